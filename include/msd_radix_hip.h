@@ -1,0 +1,129 @@
+/*
+ * msd_radix_hip.h -- typed, device-resident entry points of the MI355X in-place
+ * MSD radix sort (libinpmsdradix_hip.so).  Plain C ABI: pointers and sizes only.
+ *
+ * The reference exposes one host-pointer call (include/msb_64.h:37-39) and leaks
+ * its building blocks as accidental global symbols.  The
+ * entry points below are the device-side counterparts of those building blocks;
+ * each one names the reference function it stands in for (paths relative to
+ * /root/reference).
+ *
+ * All d_* pointers are DEVICE pointers on the context's device.  Every call is
+ * asynchronous on the context's stream unless it returns a value to the host
+ * (documented per call).  Return value: 0 on success, a negative MSD_E* code
+ * otherwise; msd_last_error() gives the message.
+ */
+#ifndef MSD_RADIX_HIP_H_
+#define MSD_RADIX_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msd_ctx msd_ctx;
+
+enum {
+	MSD_OK = 0,
+	MSD_EINVAL = -1,   /* bad argument (null pointer, misaligned buffer, bad bit range) */
+	MSD_ENOMEM = -2,   /* workspace allocation failed */
+	MSD_EHIP = -3,     /* a HIP runtime call failed */
+	MSD_EINTERNAL = -4 /* an internal invariant check failed (bug) */
+};
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Create a sorting context on `device`; `stream` is a hipStream_t (NULL = the
+ * default stream).  The context owns the auxiliary workspace (block map, block
+ * lists, stripe leftovers; about 3-5 % of the data size, grown on demand and
+ * reused between calls). */
+int msd_create(msd_ctx **ctx, int device, void *stream);
+int msd_destroy(msd_ctx *ctx);
+int msd_set_stream(msd_ctx *ctx, void *stream);
+/* Pre-allocate the workspace for sorting n elements of key_bytes (+val_bytes)
+ * so that the first timed call does not allocate. */
+int msd_reserve(msd_ctx *ctx, uint64_t n, int key_bytes, int val_bytes);
+uint64_t msd_workspace_bytes(const msd_ctx *ctx);
+const char *msd_last_error(const msd_ctx *ctx);
+const char *msd_version(void);
+
+/* ---- the sort (reference: sort() src/msb_64.c:2261, core :2232-2244) ----- */
+
+/* In-place MSD radix sort of n keys in device memory.  Keys must be aligned to
+ * 16 bytes (the reference asserts the same, src/msb_64.c:2273-2276). */
+int msd_sort_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n);
+int msd_sort_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n);
+/* (key,rid) tuples in two arrays, the reference's layout (SoA, 64-bit each).
+ * Unstable like the reference: equal keys may appear in any order. */
+int msd_sort_pairs_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n);
+/* Same, restricted to key bits [0, end_bit): bits at and above end_bit must be
+ * equal in all keys (what the reference's `bits` argument of schedule_passes
+ * means, src/msb_64.c:1334, :2242 passes 58). */
+int msd_sort_u32_bits(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, int end_bit);
+int msd_sort_u64_bits(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, int end_bit);
+int msd_sort_pairs_u64_bits(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n, int end_bit);
+
+/* ---- building blocks ----------------------------------------------------- */
+
+/* count[(key >> shift) & (2^radix_bits - 1)]++ over n keys; d_count has
+ * 2^radix_bits uint64 entries and is zeroed first; radix_bits <= 12.
+ * Reference: histogram() src/msb_64.c:701-738. */
+int msd_histogram_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n,
+		      unsigned shift, unsigned radix_bits, uint64_t *d_count);
+int msd_histogram_u64(msd_ctx *ctx, const uint64_t *d_keys, uint64_t n,
+		      unsigned shift, unsigned radix_bits, uint64_t *d_count);
+
+/* Device-wide exclusive prefix sum (single pass, decoupled look-back).
+ * Reference: the bucket-offset prefix sums src/msb_64.c:747-750, 799-823 and
+ * the cross-thread offset computation 1076-1082.  d_out may equal d_in. */
+int msd_exclusive_scan_u64(msd_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n);
+
+/* One in-place digit pass: permute keys so that they are grouped by
+ * digit = (key >> shift) & (2^radix_bits - 1), buckets in ascending digit order
+ * (unstable).  radix_bits <= 8.  If d_count != NULL it receives the 2^radix_bits
+ * bucket sizes (uint64).  Reference: histogram + partition_ip / partition_ip_buf,
+ * src/msb_64.c:1023-1027 (740-770, 785-978). */
+int msd_partition_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n,
+		      unsigned shift, unsigned radix_bits, uint64_t *d_count);
+int msd_partition_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n,
+		      unsigned shift, unsigned radix_bits, uint64_t *d_count);
+int msd_partition_pairs_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n,
+			    unsigned shift, unsigned radix_bits, uint64_t *d_count);
+
+/* Verifier, the device form of check() (src/msb_64.c:2432-2505): counts order
+ * violations (key[i] < key[i-1]) and, when d_rids != NULL, key != rid
+ * mismatches; returns wrap-around sum and xor of the keys.  Synchronous (the
+ * three results are written to host memory). */
+int msd_check_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n,
+		  uint64_t *violations, uint64_t *sum, uint64_t *xr);
+int msd_check_u64(msd_ctx *ctx, const uint64_t *d_keys, const uint64_t *d_rids, uint64_t n,
+		  uint64_t *violations, uint64_t *sum, uint64_t *xr);
+
+/* Synthetic inputs of SURVEY.md section 8d, generated on the device:
+ * key[i] = splitmix64(seed + first + i) >> 32 (u32) or the full word (u64);
+ * Zipf(theta=1): key = floor((2^32+1)^u) - 1. */
+int msd_gen_uniform_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t seed, uint64_t first);
+int msd_gen_uniform_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, uint64_t seed, uint64_t first, int shift_right);
+int msd_gen_zipf_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t seed, uint64_t first);
+int msd_gen_iota_u64(msd_ctx *ctx, uint64_t *d_vals, uint64_t n, uint64_t first);
+
+/* ---- phase report (reference: description[]/times[], src/msb_64.c:2402-2412) */
+
+/* Enable per-phase hipEvent timing for subsequent sorts on this context
+ * (adds synchronisation; off by default). */
+int msd_set_profiling(msd_ctx *ctx, int enabled);
+/* Number of phases recorded by the last sort; names/us arrays of that length. */
+int msd_phase_count(const msd_ctx *ctx);
+const char *msd_phase_name(const msd_ctx *ctx, int i);
+double msd_phase_us(const msd_ctx *ctx, int i);
+/* Counters of the last sort: rounds of in-place partitioning, blocks moved,
+ * small segments, ... (for tests and DESIGN.md tables). */
+int msd_stat(const msd_ctx *ctx, const char *name, uint64_t *value);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

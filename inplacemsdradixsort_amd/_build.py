@@ -1,0 +1,50 @@
+"""Build recipe of the HIP library (gfx950 only, in tree).
+
+``build()`` compiles ``csrc/*.hip`` into ``libinpmsdradix_hip.so`` next to this
+file with ``hipcc --offload-arch=gfx950``.  hipcc cross-compiles without a GPU,
+so this also runs in the CPU-only build container.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
+SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
+DEPS = SOURCES + ["msd_device.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
+                  os.path.join("..", "..", "include", "msb_64.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
+         "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built")
+
+
+def stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile the library if it is missing or older than its sources."""
+    if not force and not stale():
+        return LIB
+    cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

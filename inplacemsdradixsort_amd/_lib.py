@@ -1,0 +1,91 @@
+"""ctypes binding of libinpmsdradix_hip.so (the C ABI of include/*.h).
+
+Fails loudly: a missing library raises, a missing GPU makes ``msd_create`` fail
+and :class:`~inplacemsdradixsort_amd.api.MsdContext` raises.  Nothing here falls
+back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+# every symbol include/msd_radix_hip.h and include/msb_64.h declare
+EXPORTS = [
+    "msd_create", "msd_destroy", "msd_set_stream", "msd_reserve", "msd_workspace_bytes",
+    "msd_last_error", "msd_version",
+    "msd_sort_u32", "msd_sort_u64", "msd_sort_pairs_u64",
+    "msd_sort_u32_bits", "msd_sort_u64_bits", "msd_sort_pairs_u64_bits",
+    "msd_histogram_u32", "msd_histogram_u64", "msd_exclusive_scan_u64",
+    "msd_partition_u32", "msd_partition_u64", "msd_partition_pairs_u64",
+    "msd_check_u32", "msd_check_u64",
+    "msd_gen_uniform_u32", "msd_gen_uniform_u64", "msd_gen_zipf_u32", "msd_gen_iota_u64",
+    "msd_set_profiling", "msd_phase_count", "msd_phase_name", "msd_phase_us", "msd_stat",
+    "sort", "mamalloc", "check",
+]
+
+_lib = None
+
+_vp = C.c_void_p
+_u64 = C.c_uint64
+_u64p = C.POINTER(C.c_uint64)
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and _build.stale():
+        _build.build()
+    if not os.path.exists(_build.LIB):
+        raise RuntimeError(f"{_build.LIB} is missing: run inplacemsdradixsort_amd._build.build()")
+    try:  # share the process's HIP runtime with torch when torch is in use
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    L = C.CDLL(_build.LIB, mode=C.RTLD_GLOBAL if False else C.DEFAULT_MODE)
+    L.msd_create.argtypes = [C.POINTER(_vp), C.c_int, _vp]
+    L.msd_destroy.argtypes = [_vp]
+    L.msd_set_stream.argtypes = [_vp, _vp]
+    L.msd_reserve.argtypes = [_vp, _u64, C.c_int, C.c_int]
+    L.msd_workspace_bytes.argtypes = [_vp]
+    L.msd_workspace_bytes.restype = _u64
+    L.msd_last_error.argtypes = [_vp]
+    L.msd_last_error.restype = C.c_char_p
+    L.msd_version.restype = C.c_char_p
+    for f in ("msd_sort_u32", "msd_sort_u64"):
+        getattr(L, f).argtypes = [_vp, _vp, _u64]
+    L.msd_sort_pairs_u64.argtypes = [_vp, _vp, _vp, _u64]
+    for f in ("msd_sort_u32_bits", "msd_sort_u64_bits"):
+        getattr(L, f).argtypes = [_vp, _vp, _u64, C.c_int]
+    L.msd_sort_pairs_u64_bits.argtypes = [_vp, _vp, _vp, _u64, C.c_int]
+    for f in ("msd_histogram_u32", "msd_histogram_u64"):
+        getattr(L, f).argtypes = [_vp, _vp, _u64, C.c_uint, C.c_uint, _vp]
+    L.msd_exclusive_scan_u64.argtypes = [_vp, _vp, _vp, _u64]
+    for f in ("msd_partition_u32", "msd_partition_u64"):
+        getattr(L, f).argtypes = [_vp, _vp, _u64, C.c_uint, C.c_uint, _vp]
+    L.msd_partition_pairs_u64.argtypes = [_vp, _vp, _vp, _u64, C.c_uint, C.c_uint, _vp]
+    L.msd_check_u32.argtypes = [_vp, _vp, _u64, _u64p, _u64p, _u64p]
+    L.msd_check_u64.argtypes = [_vp, _vp, _vp, _u64, _u64p, _u64p, _u64p]
+    L.msd_gen_uniform_u32.argtypes = [_vp, _vp, _u64, _u64, _u64]
+    L.msd_gen_uniform_u64.argtypes = [_vp, _vp, _u64, _u64, _u64, C.c_int]
+    L.msd_gen_zipf_u32.argtypes = [_vp, _vp, _u64, _u64, _u64]
+    L.msd_gen_iota_u64.argtypes = [_vp, _vp, _u64, _u64]
+    L.msd_set_profiling.argtypes = [_vp, C.c_int]
+    L.msd_phase_count.argtypes = [_vp]
+    L.msd_phase_name.argtypes = [_vp, C.c_int]
+    L.msd_phase_name.restype = C.c_char_p
+    L.msd_phase_us.argtypes = [_vp, C.c_int]
+    L.msd_phase_us.restype = C.c_double
+    L.msd_stat.argtypes = [_vp, C.c_char_p, _u64p]
+    # reference surface (include/msb_64.h)
+    L.sort.argtypes = [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int, C.c_double,
+                       C.POINTER(C.c_char_p), _u64p]
+    L.sort.restype = None
+    L.mamalloc.argtypes = [C.c_size_t]
+    L.mamalloc.restype = _vp
+    L.check.argtypes = [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int]
+    L.check.restype = _u64
+    _lib = L
+    return L

@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+The reference is a C library with one public call, ``sort(keys, rids, size,
+threads, numa, fudge, description, times)`` (include/msb_64.h:37-39) plus
+``mamalloc`` and the test hook ``check`` (src/msb_64.c:2470).  :func:`sort`,
+:func:`mamalloc` and :func:`check` below keep those names, argument meaning and
+error behaviour on numpy host arrays; :class:`MsdContext` wraps the typed
+device-resident entry points of include/msd_radix_hip.h on torch tensors (torch
+only supplies device memory and the stream).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+
+
+class MsdError(RuntimeError):
+    pass
+
+
+def _torch():
+    import torch
+    return torch
+
+
+class MsdContext:
+    """One sorting context (device + stream + auxiliary workspace)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.msd_create(C.byref(h), device, C.c_void_p(stream or 0))
+        if rc != 0 or not h:
+            raise MsdError(f"msd_create(device={device}) failed with {rc}: no usable HIP device "
+                           "(this library has no CPU fallback)")
+        self._h = h
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.msd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    def _ok(self, rc: int) -> None:
+        if rc != 0:
+            raise MsdError(f"error {rc}: {self._L.msd_last_error(self._h).decode()}")
+
+    def _ptr(self, t, dtype_size: int) -> C.c_void_p:
+        torch = _torch()
+        if not t.is_cuda or t.device.index != self.device:
+            raise MsdError("tensor must live on the context's GPU")
+        if not t.is_contiguous() or t.element_size() != dtype_size:
+            raise MsdError("tensor must be contiguous with the expected element size")
+        return C.c_void_p(t.data_ptr())
+
+    def use_torch_stream(self) -> None:
+        torch = _torch()
+        self._ok(self._L.msd_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def reserve(self, n: int, key_bytes: int, val_bytes: int = 0) -> None:
+        self._ok(self._L.msd_reserve(self._h, n, key_bytes, val_bytes))
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self._L.msd_workspace_bytes(self._h))
+
+    # ---- the sort
+    def sort_u32(self, keys, end_bit: int = 32) -> None:
+        self._ok(self._L.msd_sort_u32_bits(self._h, self._ptr(keys, 4), keys.numel(), end_bit))
+
+    def sort_u64(self, keys, end_bit: int = 64) -> None:
+        self._ok(self._L.msd_sort_u64_bits(self._h, self._ptr(keys, 8), keys.numel(), end_bit))
+
+    def sort_pairs_u64(self, keys, rids, end_bit: int = 64) -> None:
+        if keys.numel() != rids.numel():
+            raise MsdError("keys and rids differ in length")
+        self._ok(self._L.msd_sort_pairs_u64_bits(self._h, self._ptr(keys, 8), self._ptr(rids, 8), keys.numel(), end_bit))
+
+    # ---- building blocks
+    def histogram(self, keys, shift: int, radix_bits: int):
+        torch = _torch()
+        out = torch.empty(1 << radix_bits, dtype=torch.int64, device=keys.device)
+        f = self._L.msd_histogram_u32 if keys.element_size() == 4 else self._L.msd_histogram_u64
+        self._ok(f(self._h, self._ptr(keys, keys.element_size()), keys.numel(), shift, radix_bits, C.c_void_p(out.data_ptr())))
+        return out
+
+    def exclusive_scan(self, x):
+        torch = _torch()
+        out = torch.empty_like(x)
+        self._ok(self._L.msd_exclusive_scan_u64(self._h, self._ptr(x, 8), C.c_void_p(out.data_ptr()), x.numel()))
+        return out
+
+    def partition(self, keys, shift: int, radix_bits: int, rids=None):
+        """One in-place digit pass; returns the bucket sizes (int64 tensor)."""
+        torch = _torch()
+        cnt = torch.zeros(1 << radix_bits, dtype=torch.int64, device=keys.device)
+        if rids is not None:
+            self._ok(self._L.msd_partition_pairs_u64(self._h, self._ptr(keys, 8), self._ptr(rids, 8), keys.numel(),
+                                                      shift, radix_bits, C.c_void_p(cnt.data_ptr())))
+        elif keys.element_size() == 4:
+            self._ok(self._L.msd_partition_u32(self._h, self._ptr(keys, 4), keys.numel(), shift, radix_bits, C.c_void_p(cnt.data_ptr())))
+        else:
+            self._ok(self._L.msd_partition_u64(self._h, self._ptr(keys, 8), keys.numel(), shift, radix_bits, C.c_void_p(cnt.data_ptr())))
+        return cnt
+
+    def check(self, keys, rids=None) -> Tuple[int, int, int]:
+        """(violations, sum, xor): device form of the reference's check()."""
+        v, s, x = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        if keys.element_size() == 4:
+            self._ok(self._L.msd_check_u32(self._h, self._ptr(keys, 4), keys.numel(), C.byref(v), C.byref(s), C.byref(x)))
+        else:
+            rp = self._ptr(rids, 8) if rids is not None else C.c_void_p(0)
+            self._ok(self._L.msd_check_u64(self._h, self._ptr(keys, 8), rp, keys.numel(), C.byref(v), C.byref(s), C.byref(x)))
+        return int(v.value), int(s.value), int(x.value)
+
+    # ---- synthetic inputs
+    def gen_uniform_u32(self, keys, seed: int = 0x5EED0001, first: int = 0) -> None:
+        self._ok(self._L.msd_gen_uniform_u32(self._h, self._ptr(keys, 4), keys.numel(), seed, first))
+
+    def gen_uniform_u64(self, keys, seed: int = 0x5EED0005, first: int = 0, shift_right: int = 0) -> None:
+        self._ok(self._L.msd_gen_uniform_u64(self._h, self._ptr(keys, 8), keys.numel(), seed, first, shift_right))
+
+    def gen_zipf_u32(self, keys, seed: int = 0x5EED0003, first: int = 0) -> None:
+        self._ok(self._L.msd_gen_zipf_u32(self._h, self._ptr(keys, 4), keys.numel(), seed, first))
+
+    def gen_iota_u64(self, vals, first: int = 0) -> None:
+        self._ok(self._L.msd_gen_iota_u64(self._h, self._ptr(vals, 8), vals.numel(), first))
+
+    # ---- phase report
+    def set_profiling(self, on: bool) -> None:
+        self._ok(self._L.msd_set_profiling(self._h, int(on)))
+
+    def phases(self) -> List[Tuple[str, float]]:
+        n = self._L.msd_phase_count(self._h)
+        return [(self._L.msd_phase_name(self._h, i).decode(), float(self._L.msd_phase_us(self._h, i))) for i in range(n)]
+
+    def stats(self) -> Dict[str, int]:
+        out = {}
+        for name in ("rounds", "parents", "stripes", "children", "slots", "holes", "chain_steps",
+                     "small_segments", "workspace_bytes"):
+            v = C.c_uint64()
+            if self._L.msd_stat(self._h, name.encode(), C.byref(v)) == 0:
+                out[name] = int(v.value)
+        return out
+
+
+# ---------------------------------------------------------------------------
+# the reference's own surface, on host numpy arrays
+# ---------------------------------------------------------------------------
+
+_u64p = C.POINTER(C.c_uint64)
+
+
+def mamalloc(n_bytes: int) -> np.ndarray:
+    """64-byte aligned host buffer, as the reference's mamalloc (src/msb_64.c:111-115)."""
+    L = _lib.load()
+    p = L.mamalloc(n_bytes)
+    if not p:
+        raise MemoryError(n_bytes)
+    buf = (C.c_uint8 * n_bytes).from_address(p)
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    return arr  # freed by the C library's allocator only at process exit (tests use small sizes)
+
+
+def sort(keys: Sequence[np.ndarray], rids: Sequence[np.ndarray], size: Sequence[int], threads: int = 64,
+         numa: Optional[int] = None, fudge: float = 1.0):
+    """``sort(keys, rids, size, threads, numa, fudge, description, times)`` of
+    include/msb_64.h:37-39 on lists of uint64 numpy arrays (sorted in place).
+    Returns (description, times) as the reference fills them."""
+    L = _lib.load()
+    numa = len(keys) if numa is None else numa
+    for a in list(keys) + list(rids):
+        if a.dtype != np.uint64 or not a.flags.c_contiguous:
+            raise MsdError("arrays must be contiguous uint64")
+    KA = (_u64p * numa)(*[a.ctypes.data_as(_u64p) for a in keys[:numa]])
+    RA = (_u64p * numa)(*[a.ctypes.data_as(_u64p) for a in rids[:numa]])
+    sz = np.array(list(size)[:numa], dtype=np.uint64)
+    desc = (C.c_char_p * 11)()
+    times = np.zeros(10, dtype=np.uint64)
+    L.sort(KA, RA, sz.ctypes.data_as(_u64p), threads, numa, fudge, desc, times.ctypes.data_as(_u64p))
+    for i, s in enumerate(sz):
+        size[i] = int(s) if isinstance(size, list) else size[i]
+    return [d.decode() if d is not None else None for d in desc], times
+
+
+def check(keys: Sequence[np.ndarray], rids: Optional[Sequence[np.ndarray]], size: Sequence[int], numa: Optional[int] = None,
+          same: bool = True) -> int:
+    """``check(keys, rids, size, numa, same)`` of src/msb_64.c:2470: returns the key
+    checksum; aborts the process on an order or key!=rid violation, as the
+    reference's asserts do."""
+    L = _lib.load()
+    numa = len(keys) if numa is None else numa
+    KA = (_u64p * numa)(*[a.ctypes.data_as(_u64p) for a in keys[:numa]])
+    RA = (_u64p * numa)(*[a.ctypes.data_as(_u64p) for a in rids[:numa]]) if rids is not None else None
+    sz = np.array(list(size)[:numa], dtype=np.uint64)
+    return int(L.check(KA, RA, sz.ctypes.data_as(_u64p), numa, int(same)))

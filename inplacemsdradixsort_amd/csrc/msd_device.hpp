@@ -1,0 +1,1125 @@
+// msd_device.hpp -- gfx950 kernels of the in-place MSD radix sort.
+//
+// One "round" partitions every big segment ("parent") in place by one digit of
+// up to 8 bits, in three phases that mirror the reference's parallel block
+// machinery (src/msb_64.c:497-699 range_partition_to_blocks, :2022-2093 block
+// cycle-leader swap with fetch-add claims, :1220-1302 combine/inject) rather
+// than its single sequential cycle (partition_ip_buf, :785-978):
+//
+//   A  classify_kernel   each workgroup streams its stripe through LDS, appends
+//                        keys to 256 per-bucket LDS buffers (rank = LDS fetch-add)
+//                        and flushes every full buffer as one aligned 256-byte
+//                        block BEHIND its own read cursor; the digit histogram
+//                        falls out of this pass (no separate counting read).
+//   B  chains_kernel     block-granular permutation: a lane owns a hole, claims
+//                        the next misplaced block of the hole's bucket with a
+//                        fetch-add on that bucket's list cursor, moves it into
+//                        the hole and inherits the vacated slot.
+//   C  cleanup_kernel    bucket heads/tails are filled from the stripes'
+//                        partial buffers.
+// Segments that fit LDS are finished by lds_sort_kernel (stable LSD passes inside
+// LDS; ranks from wavefront ballot/popcount match-any).
+//
+// Everything here is integer/byte work bound by HBM; there is no MFMA use.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msd {
+
+constexpr int kP = 256;              // buckets per digit pass (8-bit digits)
+constexpr uint32_t kXBase = 0x80000000u; // slot ids >= kXBase live in the side block store
+constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
+
+struct NoVal {};
+
+template <typename V> struct has_val { static constexpr bool value = true; };
+template <> struct has_val<NoVal> { static constexpr bool value = false; };
+
+// Geometry per (key, payload) type.  B = elements per block (256-byte key
+// blocks), T = elements per classify tile, TH = classify threads.
+template <typename K, typename V> struct Cfg;
+template <> struct Cfg<uint32_t, NoVal> {
+	static constexpr int B = 64, T = 4096, TH = 512;
+	static constexpr int SORT_TH = 1024, SORT_KPT = 24; // LDS sort capacity 24576
+};
+template <> struct Cfg<uint64_t, NoVal> {
+	static constexpr int B = 32, T = 2048, TH = 512;
+	static constexpr int SORT_TH = 1024, SORT_KPT = 12; // 12288
+};
+template <> struct Cfg<uint64_t, uint64_t> {
+	static constexpr int B = 32, T = 1024, TH = 256;
+	static constexpr int SORT_TH = 1024, SORT_KPT = 6; // 6144
+};
+
+struct Parent {
+	uint64_t start, count;
+	uint32_t shift;      // digit = (key >> shift) & ((1 << width) - 1)
+	uint32_t width;      // 1..8
+	uint32_t child_base; // global child index of digit 0
+	uint32_t stripe_lo, stripe_hi;
+	uint32_t pad;
+};
+
+struct Stripe {
+	uint64_t begin, end; // element range; begin is B-aligned except for a parent's first stripe
+	uint64_t lo_base;    // element offset of this stripe's leftover area
+	uint32_t parent;
+	uint32_t slot_lo, slot_hi; // aligned block slots fully inside [begin, end)
+	uint32_t pad;
+};
+
+struct Segment { // a finished-partition child that still needs sorting
+	uint64_t start, count;
+	uint32_t bits; // low bits still unsorted
+	uint32_t pad;
+};
+
+struct ListEntry {
+	uint32_t slot;  // where the misplaced block sits (>= kXBase: side store)
+	uint32_t owner; // global child whose interior contains `slot`, kNoOwner for fringe
+};
+
+struct Counters { // one per sort call, zeroed per round where noted
+	uint32_t nholes;       // per round
+	uint32_t hole_cursor;  // per round
+	uint32_t next_parents; // per round
+	uint32_t nsmall;       // cumulative
+	uint32_t errors;       // cumulative: internal invariant violations
+	uint32_t chain_steps;  // cumulative (stat)
+	uint32_t pad[2];
+};
+
+// ---------------------------------------------------------------- utilities
+
+template <typename K> __device__ __forceinline__ uint32_t digit_of(K key, uint32_t shift, uint32_t mask)
+{
+	return (uint32_t)(key >> shift) & mask;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+
+// inclusive scan inside a wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		uint32_t t = __shfl_up(v, o);
+		if ((int)lane_id() >= o) v += t;
+	}
+	return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v)
+{
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		uint64_t t = __shfl_up(v, o);
+		if ((int)lane_id() >= o) v += t;
+	}
+	return v;
+}
+
+// Exclusive scan over the first 256 threads' values; every thread of the block
+// must call it (it contains barriers).  tmp: >= 5 uint32 of LDS.  Returns the
+// exclusive prefix for threads < 256 and the grand total in `total`.
+__device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *tmp, uint32_t &total)
+{
+	const uint32_t tid = threadIdx.x;
+	if (tid >= 256) v = 0;
+	uint32_t inc = wave_incl_scan(v);
+	if (tid < 256 && lane_id() == 63) tmp[tid >> 6] = inc;
+	__syncthreads();
+	uint32_t base = 0;
+	if (tid < 256) {
+		const uint32_t w = tid >> 6;
+		if (w > 0) base += tmp[0];
+		if (w > 1) base += tmp[1];
+		if (w > 2) base += tmp[2];
+	}
+	total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+	__syncthreads();
+	return base + inc - v;
+}
+__device__ __forceinline__ uint64_t block_excl_scan256_64(uint64_t v, uint64_t *tmp, uint64_t &total)
+{
+	const uint32_t tid = threadIdx.x;
+	if (tid >= 256) v = 0;
+	uint64_t inc = wave_incl_scan64(v);
+	if (tid < 256 && lane_id() == 63) tmp[tid >> 6] = inc;
+	__syncthreads();
+	uint64_t base = 0;
+	if (tid < 256) {
+		const uint32_t w = tid >> 6;
+		if (w > 0) base += tmp[0];
+		if (w > 1) base += tmp[1];
+		if (w > 2) base += tmp[2];
+	}
+	total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+	__syncthreads();
+	return base + inc - v;
+}
+
+// 16-byte vector of K
+template <typename K> struct Vec16;
+template <> struct Vec16<uint32_t> { static constexpr int N = 4; };
+template <> struct Vec16<uint64_t> { static constexpr int N = 2; };
+
+// ------------------------------------------------------------ A: classify
+
+template <typename K, typename V> struct ClassifyLds {
+	using C = Cfg<K, V>;
+	static constexpr bool HV = has_val<V>::value;
+	static constexpr size_t kbuf = (size_t)(kP * C::B + C::T) * sizeof(K); // part | ost (contiguous)
+	static constexpr size_t vbuf = HV ? (size_t)(kP * C::B + C::T) * sizeof(uint64_t) : 0;
+	static constexpr size_t head = (size_t)C::B * sizeof(K) + (HV ? (size_t)C::B * sizeof(uint64_t) : 0);
+	static constexpr int JOBS = kP + C::T / C::B + 8;
+	// meta, c, fbcnt, hc, loff : 5*kP u32 ; jobs ; tmp 8
+	static constexpr size_t small = (size_t)(5 * kP + JOBS + 8) * sizeof(uint32_t);
+	static constexpr size_t bytes = kbuf + vbuf + head + small;
+};
+
+template <typename K, typename V>
+__global__ __launch_bounds__((Cfg<K, V>::TH)) void classify_kernel(
+	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
+	const Parent *__restrict__ parents, uint8_t *__restrict__ block_map,
+	uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt, uint32_t *__restrict__ lo_off,
+	K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals, uint32_t *__restrict__ nfull)
+{
+	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
+	constexpr int B = C::B, T = C::T, TH = C::TH;
+	constexpr int VEC = Vec16<K>::N;
+	constexpr int KPT = T / TH;    // keys per thread per tile
+	constexpr int NV = KPT / VEC;  // 16-byte vectors per thread per tile
+	constexpr int LPB = B / VEC;   // lanes that move one block
+	constexpr int PB = kP * B;
+	static_assert(KPT % VEC == 0 && NV >= 1, "tile geometry");
+	using L = ClassifyLds<K, V>;
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	K *kbuf = reinterpret_cast<K *>(smem); // [0,PB) partial buffers, [PB,PB+T) block staging
+	uint64_t *vbuf = reinterpret_cast<uint64_t *>(smem + L::kbuf);
+	K *headk = reinterpret_cast<K *>(smem + L::kbuf + L::vbuf);
+	uint64_t *headv = reinterpret_cast<uint64_t *>(smem + L::kbuf + L::vbuf + (size_t)B * sizeof(K));
+	uint32_t *meta = reinterpret_cast<uint32_t *>(smem + L::kbuf + L::vbuf + L::head);
+	uint32_t *cnt = meta + kP;   // tile count per bucket
+	uint32_t *fbcnt = cnt + kP;  // full blocks flushed per bucket
+	uint32_t *hc = fbcnt + kP;   // head keys per bucket
+	uint32_t *loff = hc + kP;    // leftover offsets
+	uint32_t *jobs = loff + kP;  // flush job table
+	uint32_t *tmp = jobs + L::JOBS;
+
+	const uint32_t tid = threadIdx.x;
+	const Stripe st = stripes[blockIdx.x];
+	const Parent pa = parents[st.parent];
+	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u;
+
+	if (tid < kP) {
+		meta[tid] = 0; // fill=0, nb=0, obase=0
+		cnt[tid] = 0;
+		fbcnt[tid] = 0;
+		hc[tid] = 0;
+	}
+	const uint64_t a0 = (uint64_t)st.slot_lo * B; // first aligned position >= begin
+	// ---- head keys (only a parent's first stripe has them): parked in LDS until the end
+	const uint32_t h = (uint32_t)((a0 < st.end ? a0 : st.end) - st.begin);
+	if (tid < h) {
+		headk[tid] = keys[st.begin + tid];
+		if (HV) headv[tid] = vals[st.begin + tid];
+	}
+	__syncthreads();
+	if (tid < h) atomicAdd(&hc[digit_of(headk[tid], shift, mask)], 1u);
+
+	uint32_t wslot = st.slot_lo; // next output slot (uniform)
+	uint32_t fill_r = 0;         // thread d<kP: fill of bucket d (register copy)
+	uint32_t fb_r = 0;
+
+	K kreg[KPT];
+	uint64_t vreg[HV ? KPT : 1];
+
+	auto load_tile = [&](uint64_t pos, K *kr, uint64_t *vr) {
+#pragma unroll
+		for (int v = 0; v < NV; ++v) {
+			const uint64_t idx = pos + (uint64_t)(v * TH + tid) * VEC;
+			if (idx + VEC <= st.end) {
+				if constexpr (sizeof(K) == 4) {
+					const uint4 q = *reinterpret_cast<const uint4 *>(keys + idx);
+					kr[v * VEC + 0] = q.x; kr[v * VEC + 1] = q.y; kr[v * VEC + 2] = q.z; kr[v * VEC + 3] = q.w;
+				} else {
+					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + idx);
+					kr[v * VEC + 0] = q.x; kr[v * VEC + 1] = q.y;
+				}
+				if constexpr (HV) {
+					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + idx);
+					vr[v * VEC + 0] = q.x; vr[v * VEC + 1] = q.y;
+				}
+			} else {
+#pragma unroll
+				for (int e = 0; e < VEC; ++e) {
+					if (idx + e < st.end) {
+						kr[v * VEC + e] = keys[idx + e];
+						if constexpr (HV) vr[v * VEC + e] = vals[idx + e];
+					}
+				}
+			}
+		}
+	};
+
+	uint64_t pos = a0;
+	K knext[KPT];
+	uint64_t vnext[HV ? KPT : 1];
+	if (pos < st.end) load_tile(pos, knext, vnext);
+
+	while (pos < st.end) {
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			kreg[i] = knext[i];
+			if constexpr (HV) vreg[i] = vnext[i];
+		}
+		const uint64_t npos = pos + T;
+		if (npos < st.end) load_tile(npos, knext, vnext); // prefetch: original data beyond this tile
+
+		// ---- rank every key inside its bucket for this tile
+		uint32_t dr[KPT]; // digit | rank<<8
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			const uint64_t idx = pos + (uint64_t)((i / VEC) * TH + tid) * VEC + (i % VEC);
+			if (idx < st.end) {
+				const uint32_t d = digit_of(kreg[i], shift, mask);
+				const uint32_t r = atomicAdd(&cnt[d], 1u);
+				dr[i] = d | (r << 8);
+			} else
+				dr[i] = 0xFFFFFFFFu;
+		}
+		__syncthreads();
+
+		// ---- per bucket: how many blocks complete with this tile
+		uint32_t nb_r = 0, L_r = 0, pk = 0;
+		if (tid < kP) {
+			L_r = fill_r + cnt[tid];
+			nb_r = L_r / B;
+			pk = nb_r | ((nb_r ? nb_r - 1 : 0) << 16);
+		}
+		uint32_t tot;
+		const uint32_t ex = block_excl_scan256(pk, tmp, tot);
+		const uint32_t nbtot = tot & 0xFFFFu;
+		if (tid < kP) {
+			const uint32_t bbase = ex & 0xFFFFu, ob = ex >> 16; // ob in blocks
+			meta[tid] = fill_r | (nb_r << 8) | (ob << 20);
+			for (uint32_t q = 0; q < nb_r; ++q)
+				jobs[bbase + q] = (q == 0 ? tid * B : PB + (ob + q - 1) * B) | (tid << 24);
+		}
+		__syncthreads();
+
+		// ---- scatter: top up partial buffers, stage whole extra blocks, defer remainders
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			if (dr[i] != 0xFFFFFFFFu) {
+				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
+				const uint32_t m = meta[d];
+				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
+				uint32_t at;
+				if (nb == 0 || vp < (uint32_t)B)
+					at = d * B + vp;
+				else if (vp < nb * B)
+					at = PB + (m >> 20) * B + (vp - B);
+				else
+					at = 0xFFFFFFFFu; // remainder of a flushed bucket: written after the flush
+				if (at != 0xFFFFFFFFu) {
+					kbuf[at] = kreg[i];
+					if constexpr (HV) vbuf[at] = vreg[i];
+					dr[i] = 0xFFFFFFFEu; // done
+				}
+			}
+		}
+		__syncthreads();
+
+		// ---- flush nbtot blocks to consecutive slots behind the read cursor
+		for (uint32_t g = tid / LPB; g < nbtot; g += TH / LPB) {
+			const uint32_t j = jobs[g];
+			const uint32_t src = (j & 0xFFFFFFu) + (tid % LPB) * VEC;
+			const uint64_t dst = (uint64_t)(wslot + g) * B + (tid % LPB) * VEC;
+			*reinterpret_cast<uint4 *>(keys + dst) = *reinterpret_cast<const uint4 *>(kbuf + src);
+			if constexpr (HV)
+				*reinterpret_cast<uint4 *>(vals + dst) = *reinterpret_cast<const uint4 *>(vbuf + src);
+			if ((tid % LPB) == 0) block_map[wslot + g] = (uint8_t)(j >> 24);
+		}
+		__syncthreads();
+
+		// ---- deferred remainders go to the front of their (now empty) buffer
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			if (dr[i] < 0xFFFFFFFEu) {
+				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
+				const uint32_t m = meta[d];
+				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
+				kbuf[d * B + vp - nb * B] = kreg[i];
+				if constexpr (HV) vbuf[d * B + vp - nb * B] = vreg[i];
+			}
+		}
+		if (tid < kP) {
+			fill_r = L_r - nb_r * B;
+			fb_r += nb_r;
+			cnt[tid] = 0;
+		}
+		wslot += nbtot;
+		pos = npos;
+		__syncthreads();
+		if (tid < kP) meta[tid] = fill_r; // keeps meta coherent for the final write-out
+	}
+	__syncthreads();
+
+	// ---- stripe epilogue: leftovers (partial buffers + head keys) to the side area
+	uint32_t lc = 0;
+	if (tid < kP) lc = fill_r + hc[tid];
+	uint32_t ltot;
+	const uint32_t lex = block_excl_scan256(lc, tmp, ltot);
+	const size_t so = (size_t)blockIdx.x * kP + tid;
+	if (tid < kP) {
+		loff[tid] = lex;
+		lo_cnt[so] = lc;
+		lo_off[so] = lex;
+		fb[so] = fb_r;
+		hc[tid] = 0; // reused as head cursor
+	}
+	if (tid == 0) nfull[blockIdx.x] = wslot - st.slot_lo;
+	__syncthreads();
+	for (uint32_t idx = tid; idx < (uint32_t)PB; idx += TH) {
+		const uint32_t d = idx / B, j = idx % B;
+		if (j < (meta[d] & 0xFFu)) {
+			lo_keys[st.lo_base + loff[d] + j] = kbuf[idx];
+			if constexpr (HV) lo_vals[st.lo_base + loff[d] + j] = vbuf[idx];
+		}
+	}
+	if (tid < h) {
+		const uint32_t d = digit_of(headk[tid], shift, mask);
+		const uint32_t r = atomicAdd(&hc[d], 1u);
+		const uint64_t at = st.lo_base + loff[d] + (meta[d] & 0xFFu) + r;
+		lo_keys[at] = headk[tid];
+		if constexpr (HV) lo_vals[at] = headv[tid];
+	}
+}
+
+// ------------------------------------------------- child geometry per parent
+
+struct ChildArrays {
+	uint64_t *start;  // absolute first element
+	uint64_t *count;
+	uint32_t *F;      // full blocks produced for the child
+	uint32_t *is;     // first interior slot
+	uint32_t *I;      // interior slots (<= F)
+	uint32_t *lsum;   // leftover elements from all stripes
+	uint32_t *n_int;  // misplaced blocks sitting in some interior
+	uint32_t *n_fr;   // misplaced blocks sitting in fringe slots
+	uint32_t *n_int0; // n_int before the eviction adjustment
+	uint32_t *cur_int, *cur_fr; // scatter cursors
+	uint64_t *list_len, *list_base;
+	uint32_t *rpos;   // claim cursor of the child's list
+	uint32_t *flags;  // bit0 evict, bit1 excess
+};
+
+template <int B>
+__global__ __launch_bounds__(256) void child_scan_kernel(const Parent *__restrict__ parents,
+	const uint32_t *__restrict__ fb, const uint32_t *__restrict__ lo_cnt,
+	uint32_t *__restrict__ lo_dst, ChildArrays ca)
+{
+	__shared__ uint64_t tmp[8];
+	const Parent pa = parents[blockIdx.x];
+	const uint32_t d = threadIdx.x;
+	uint64_t F = 0, ls = 0;
+	for (uint32_t s = pa.stripe_lo; s < pa.stripe_hi; ++s) {
+		const size_t o = (size_t)s * kP + d;
+		F += fb[o];
+		lo_dst[o] = (uint32_t)ls;
+		ls += lo_cnt[o];
+	}
+	const uint64_t c = F * B + ls;
+	uint64_t total;
+	const uint64_t ex = block_excl_scan256_64(c, tmp, total);
+	if (d < (1u << pa.width)) {
+		const uint32_t ci = pa.child_base + d;
+		const uint64_t st = pa.start + ex, en = st + c;
+		const uint64_t is = (st + B - 1) / B, ie = en / B;
+		const uint64_t room = ie > is ? ie - is : 0;
+		const uint64_t I = F < room ? F : room;
+		ca.start[ci] = st;
+		ca.count[ci] = c;
+		ca.F[ci] = (uint32_t)F;
+		ca.is[ci] = (uint32_t)is;
+		ca.I[ci] = (uint32_t)I;
+		ca.lsum[ci] = (uint32_t)ls;
+		ca.n_int[ci] = 0;
+		ca.n_fr[ci] = 0;
+		ca.cur_int[ci] = 0;
+		ca.cur_fr[ci] = 0;
+		ca.rpos[ci] = 0;
+	}
+}
+
+// owner of slot i among the W children of a parent (LDS copies of is/ie), -1 if fringe
+__device__ __forceinline__ int slot_owner(const uint32_t *is, const uint32_t *ie, uint32_t W, uint32_t i)
+{
+	// smallest c with ie[c] > i   (ie is non-decreasing)
+	uint32_t lo = 0, hi = W;
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (ie[mid] > i) hi = mid; else lo = mid + 1;
+	}
+	if (lo < W && is[lo] <= i) return (int)lo;
+	return -1;
+}
+
+// Pass 1 (SCATTER = false): count misplaced blocks per (child, class) and record holes.
+// Pass 2 (SCATTER = true): write the per-child lists, interior-class entries first.
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__restrict__ stripes,
+	const Parent *__restrict__ parents, const uint8_t *__restrict__ block_map,
+	const uint32_t *__restrict__ nfull, ChildArrays ca, ListEntry *__restrict__ list,
+	ListEntry *__restrict__ holes, Counters *__restrict__ ctr)
+{
+	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP];
+	const Stripe st = stripes[blockIdx.x];
+	const Parent pa = parents[st.parent];
+	const uint32_t W = 1u << pa.width, tid = threadIdx.x;
+	if (tid < W) {
+		s_is[tid] = ca.is[pa.child_base + tid];
+		s_ie[tid] = s_is[tid] + ca.I[pa.child_base + tid];
+	}
+	s_cls[0][tid] = 0;
+	s_cls[1][tid] = 0;
+	__syncthreads();
+	const uint32_t nf = nfull[blockIdx.x];
+	for (uint32_t i = st.slot_lo + tid; i < st.slot_hi; i += 256) {
+		const int own = slot_owner(s_is, s_ie, W, i);
+		if (i - st.slot_lo < nf) {
+			const uint32_t d = block_map[i];
+			if ((int)d != own) {
+				const uint32_t cls = own >= 0 ? 0 : 1;
+				if (!SCATTER)
+					atomicAdd(&s_cls[cls][d], 1u);
+				else {
+					const uint32_t ci = pa.child_base + d;
+					uint32_t p;
+					uint64_t base = ca.list_base[ci];
+					if (cls == 0)
+						p = atomicAdd(&ca.cur_int[ci], 1u);
+					else {
+						p = atomicAdd(&ca.cur_fr[ci], 1u);
+						base += ca.n_int0[ci];
+					}
+					ListEntry e;
+					e.slot = i;
+					e.owner = own >= 0 ? pa.child_base + (uint32_t)own : kNoOwner;
+					list[base + p] = e;
+				}
+			}
+		} else if (!SCATTER && own >= 0) {
+			const uint32_t p = atomicAdd(&ctr->nholes, 1u);
+			ListEntry e;
+			e.slot = i;
+			e.owner = pa.child_base + (uint32_t)own;
+			holes[p] = e;
+		}
+	}
+	if (!SCATTER) {
+		__syncthreads();
+		if (tid < W) {
+			if (s_cls[0][tid]) atomicAdd(&ca.n_int[pa.child_base + tid], s_cls[0][tid]);
+			if (s_cls[1][tid]) atomicAdd(&ca.n_fr[pa.child_base + tid], s_cls[1][tid]);
+		}
+	}
+}
+
+// Per child: list length, eviction / excess decisions.
+__global__ __launch_bounds__(256) void list_prepare_kernel(uint32_t nchildren, ChildArrays ca)
+{
+	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+	if (ci >= nchildren) return;
+	const uint32_t ni = ca.n_int[ci], nf = ca.n_fr[ci];
+	const uint32_t ev = (ni > 0 && nf == 0) ? 1u : 0u;
+	const uint32_t ex = ca.F[ci] > ca.I[ci] ? 2u : 0u;
+	ca.n_int0[ci] = ni;
+	ca.n_int[ci] = ni - ev; // entries [0, n_int) keep a chain going, the rest end it
+	ca.list_len[ci] = ni + nf;
+	ca.flags[ci] = ev | ex;
+}
+
+// address of a block slot: real slots inside the key array, virtual ones in the side store
+template <typename T, int B>
+__device__ __forceinline__ T *slot_ptr(T *base, T *xbase, uint32_t slot)
+{
+	return slot < kXBase ? base + (uint64_t)slot * B : xbase + (uint64_t)(slot - kXBase) * B;
+}
+
+// One wave per child that needs it: (a) evict one interior-class block to the side
+// store so that the child's list ends with a chain-terminating entry, (b) open the
+// virtual slot that takes the child's excess block.
+template <typename K, typename V>
+__global__ __launch_bounds__(64) void evict_kernel(uint32_t nchildren, ChildArrays ca,
+	ListEntry *__restrict__ list, ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
+	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals)
+{
+	constexpr int B = Cfg<K, V>::B;
+	constexpr bool HV = has_val<V>::value;
+	const uint32_t ci = blockIdx.x;
+	if (ci >= nchildren) return;
+	const uint32_t fl = ca.flags[ci];
+	if (fl == 0) return;
+	const uint32_t lane = threadIdx.x;
+	if (fl & 1u) {
+		const uint64_t e = ca.list_base[ci] + ca.n_int0[ci] - 1;
+		const ListEntry ent = list[e];
+		const uint32_t xs = kXBase + 2 * ci;
+		for (uint32_t j = lane; j < (uint32_t)B; j += 64) {
+			slot_ptr<K, B>(keys, xkeys, xs)[j] = slot_ptr<K, B>(keys, xkeys, ent.slot)[j];
+			if constexpr (HV)
+				slot_ptr<uint64_t, B>(vals, xvals, xs)[j] = slot_ptr<uint64_t, B>(vals, xvals, ent.slot)[j];
+		}
+		if (lane == 0) {
+			ListEntry ne;
+			ne.slot = xs;
+			ne.owner = kNoOwner;
+			list[e] = ne;
+			const uint32_t p = atomicAdd(&ctr->nholes, 1u);
+			holes[p] = ent; // the vacated slot, owned by the interior it lies in
+		}
+	}
+	if ((fl & 2u) && lane == 0) {
+		const uint32_t p = atomicAdd(&ctr->nholes, 1u);
+		ListEntry hsl;
+		hsl.slot = kXBase + 2 * ci + 1;
+		hsl.owner = ci;
+		holes[p] = hsl;
+	}
+}
+
+// ------------------------------------------------------ B: block permutation
+
+// Every lane runs one chain: own a hole -> claim the next misplaced block of the
+// hole's bucket (fetch-add on the bucket's list cursor) -> the wave moves the 64
+// claimed blocks -> the vacated slot is the lane's next hole, unless the claimed
+// entry was fringe-class, which ends the chain.  No lane ever waits for another.
+template <typename K, typename V>
+__global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListEntry *__restrict__ list,
+	const ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
+	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals)
+{
+	constexpr int B = Cfg<K, V>::B;
+	constexpr bool HV = has_val<V>::value;
+	constexpr int VEC = Vec16<K>::N;
+	constexpr int LPB = B / VEC;      // lanes per block (16)
+	constexpr int BPI = 64 / LPB;     // blocks per wave instruction (4)
+	constexpr int NI = 64 / BPI;      // instructions to move 64 blocks (16)
+	const uint32_t lane = lane_id();
+	const uint32_t nholes = ctr->nholes;
+	uint32_t hole = 0, owner = 0;
+	bool active = false, exhausted = false;
+	uint32_t steps = 0;
+
+	for (;;) {
+		// ---- lanes without a hole fetch the next chain start
+		if (!exhausted) {
+			const uint64_t need = __ballot(!active);
+			if (need) {
+				const uint32_t n = __popcll(need);
+				uint32_t base = 0;
+				if (lane == (uint32_t)(__ffsll((long long)need) - 1)) base = atomicAdd(&ctr->hole_cursor, n);
+				base = __shfl(base, __ffsll((long long)need) - 1);
+				if (!active) {
+					const uint32_t my = base + __popcll(need & ((1ull << lane) - 1ull));
+					if (my < nholes) {
+						const ListEntry e = holes[my];
+						hole = e.slot;
+						owner = e.owner;
+						active = true;
+					}
+				}
+				if (base + n >= nholes) exhausted = true;
+			}
+		}
+		const uint64_t act = __ballot(active);
+		if (!act) break;
+
+		// ---- claim one source block per active lane
+		uint32_t src = 0, src_owner = kNoOwner;
+		bool last = false;
+		if (active) {
+			const uint32_t idx = atomicAdd(&ca.rpos[owner], 1u);
+			const uint32_t len = (uint32_t)ca.list_len[owner];
+			if (idx >= len) { // cannot happen when the bookkeeping is right
+				atomicAdd(&ctr->errors, 1u);
+				active = false;
+			} else {
+				const ListEntry e = list[ca.list_base[owner] + idx];
+				src = e.slot;
+				src_owner = e.owner;
+				last = idx >= ca.n_int[owner];
+			}
+		}
+		const uint64_t mv = __ballot(active);
+		++steps;
+
+		// ---- move the claimed blocks: lane group g of instruction i serves chain i*BPI+g
+		uint4 kd[NI];
+		uint4 vd[HV ? NI : 1];
+		const uint32_t sub = lane % LPB;
+#pragma unroll
+		for (int i = 0; i < NI; ++i) {
+			const int chain = i * BPI + (int)(lane / LPB);
+			const uint32_t s = __shfl(src, chain);
+			if ((mv >> chain) & 1ull) {
+				kd[i] = *reinterpret_cast<const uint4 *>(slot_ptr<K, B>(keys, xkeys, s) + sub * VEC);
+				if constexpr (HV)
+					vd[i] = *reinterpret_cast<const uint4 *>(slot_ptr<uint64_t, B>(vals, xvals, s) + sub * VEC);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NI; ++i) {
+			const int chain = i * BPI + (int)(lane / LPB);
+			const uint32_t hdst = __shfl(hole, chain);
+			if ((mv >> chain) & 1ull) {
+				*reinterpret_cast<uint4 *>(slot_ptr<K, B>(keys, xkeys, hdst) + sub * VEC) = kd[i];
+				if constexpr (HV)
+					*reinterpret_cast<uint4 *>(slot_ptr<uint64_t, B>(vals, xvals, hdst) + sub * VEC) = vd[i];
+			}
+		}
+		if (active) {
+			if (last)
+				active = false;
+			else {
+				hole = src;
+				owner = src_owner;
+			}
+		}
+	}
+	if (lane == 0 && steps) atomicAdd(&ctr->chain_steps, steps);
+}
+
+// every list must have been consumed exactly
+__global__ __launch_bounds__(256) void chains_verify_kernel(uint32_t nchildren, ChildArrays ca, Counters *ctr)
+{
+	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+	if (ci >= nchildren) return;
+	if (ca.rpos[ci] != (uint32_t)ca.list_len[ci]) atomicAdd(&ctr->errors, 1u);
+}
+
+// ------------------------------------------------------------- C: cleanup
+
+// position of logical fringe offset o of a child
+template <int B>
+__device__ __forceinline__ uint64_t fringe_pos(uint64_t start, uint32_t is, uint32_t I, uint64_t o)
+{
+	if (I == 0) return start + o;
+	const uint64_t head = (uint64_t)is * B - start;
+	return o < head ? start + o : (uint64_t)(is + I) * B + (o - head);
+}
+
+template <typename K, typename V>
+__global__ __launch_bounds__(256) void cleanup_kernel(const Stripe *__restrict__ stripes,
+	const Parent *__restrict__ parents, const uint32_t *__restrict__ lo_cnt,
+	const uint32_t *__restrict__ lo_off, const uint32_t *__restrict__ lo_dst, ChildArrays ca,
+	const K *__restrict__ lo_keys, const uint64_t *__restrict__ lo_vals,
+	K *__restrict__ keys, uint64_t *__restrict__ vals)
+{
+	constexpr int B = Cfg<K, V>::B;
+	constexpr bool HV = has_val<V>::value;
+	__shared__ uint32_t s_off[kP + 1], s_dst[kP], s_is[kP], s_I[kP];
+	__shared__ uint64_t s_start[kP];
+	const Stripe st = stripes[blockIdx.x];
+	const Parent pa = parents[st.parent];
+	const uint32_t tid = threadIdx.x, W = 1u << pa.width;
+	const size_t so = (size_t)blockIdx.x * kP + tid;
+	s_off[tid] = lo_off[so];
+	s_dst[tid] = lo_dst[so];
+	if (tid == kP - 1) s_off[kP] = lo_off[so] + lo_cnt[so];
+	if (tid < W) {
+		s_is[tid] = ca.is[pa.child_base + tid];
+		s_I[tid] = ca.I[pa.child_base + tid];
+		s_start[tid] = ca.start[pa.child_base + tid];
+	}
+	__syncthreads();
+	const uint32_t total = s_off[kP];
+	for (uint32_t idx = tid; idx < total; idx += 256) {
+		// last d with s_off[d] <= idx
+		uint32_t lo = 0, hi = kP;
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (s_off[mid] <= idx) lo = mid; else hi = mid;
+		}
+		const uint32_t d = lo;
+		const uint64_t o = (uint64_t)s_dst[d] + (idx - s_off[d]);
+		const uint64_t p = fringe_pos<B>(s_start[d], s_is[d], s_I[d], o);
+		keys[p] = lo_keys[st.lo_base + idx];
+		if constexpr (HV) vals[p] = lo_vals[st.lo_base + idx];
+	}
+}
+
+// excess blocks (one per child at most) go behind the stripes' leftovers
+template <typename K, typename V>
+__global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArrays ca,
+	const K *__restrict__ xkeys, const uint64_t *__restrict__ xvals,
+	K *__restrict__ keys, uint64_t *__restrict__ vals)
+{
+	constexpr int B = Cfg<K, V>::B;
+	constexpr bool HV = has_val<V>::value;
+	const uint32_t ci = blockIdx.x;
+	if (ci >= nchildren || !(ca.flags[ci] & 2u)) return;
+	const uint64_t st = ca.start[ci];
+	const uint32_t is = ca.is[ci], I = ca.I[ci], ls = ca.lsum[ci];
+	for (uint32_t j = threadIdx.x; j < (uint32_t)B; j += 64) {
+		const uint64_t p = fringe_pos<B>(st, is, I, (uint64_t)ls + j);
+		keys[p] = xkeys[(uint64_t)(2 * ci + 1) * B + j];
+		if constexpr (HV) vals[p] = xvals[(uint64_t)(2 * ci + 1) * B + j];
+	}
+}
+
+// children -> next round's parents / the small-segment list / done
+__global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, ChildArrays ca,
+	uint64_t small_max, uint32_t small_cap, Segment *__restrict__ next_parents, Segment *__restrict__ small,
+	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out)
+{
+	const Parent pa = parents[blockIdx.x];
+	const uint32_t d = threadIdx.x;
+	if (d >= (1u << pa.width)) return;
+	const uint32_t ci = pa.child_base + d;
+	const uint64_t c = ca.count[ci];
+	if (count_out) count_out[ci] = c;
+	if (c <= 1 || pa.shift == 0) return;
+	Segment s;
+	s.start = ca.start[ci];
+	s.count = c;
+	s.bits = pa.shift;
+	s.pad = 0;
+	if (c > small_max)
+		next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
+	else {
+		const uint32_t at = atomicAdd(&ctr->nsmall, 1u);
+		if (at < small_cap)
+			small[at] = s;
+		else
+			atomicAdd(&ctr->errors, 1u);
+	}
+}
+
+// ------------------------------------------------------- LDS segment sort
+
+// One workgroup sorts one segment of <= SORT_TH*SORT_KPT elements on its low
+// `bits` bits: stable LSD passes of 8 bits inside LDS.  Keys live in registers in
+// wave-striped order; the per-wave rank of a key among equal digits comes from a
+// match-any built with 8 wavefront ballots and a popcount of the lower lanes.
+template <typename K, typename V>
+__global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__restrict__ keys,
+	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs)
+{
+	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
+	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, NW = TH / 64, CAP = TH * KPT;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	K *xk = reinterpret_cast<K *>(smem);
+	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
+	uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * sizeof(K) + (HV ? (size_t)CAP * 8 : 0));
+	uint32_t *dbase = wcnt + NW * kP; // 256
+	uint32_t *tmp = dbase + kP;       // 8
+	K *s_or = reinterpret_cast<K *>(tmp + 8); // [2]: OR and AND of the keys (varying-bit detection)
+
+	if (blockIdx.x >= nsegs) return;
+	const Segment sg = segs[blockIdx.x];
+	const uint32_t n = (uint32_t)sg.count;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t wbase = w * (KPT * 64);
+	const uint64_t lt_mask = (1ull << lane) - 1ull;
+
+	K kr[KPT];
+	uint64_t vr[HV ? KPT : 1];
+	K k_or = 0, k_and = ~(K)0;
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) {
+		const uint32_t idx = wbase + i * 64 + lane;
+		if (idx < n) {
+			kr[i] = keys[sg.start + idx];
+			if constexpr (HV) vr[i] = vals[sg.start + idx];
+			k_or |= kr[i];
+			k_and &= kr[i];
+		} else {
+			kr[i] = ~(K)0;
+			if constexpr (HV) vr[i] = 0;
+		}
+	}
+	// which bits vary inside the segment (passes over constant digits are skipped)
+	if (tid == 0) { s_or[0] = 0; s_or[1] = ~(K)0; }
+	__syncthreads();
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		k_or |= __shfl_xor(k_or, o);
+		k_and &= __shfl_xor(k_and, o);
+	}
+	if (lane == 0) {
+		if constexpr (sizeof(K) == 4) {
+			atomicOr(reinterpret_cast<unsigned int *>(&s_or[0]), (unsigned int)k_or);
+			atomicAnd(reinterpret_cast<unsigned int *>(&s_or[1]), (unsigned int)k_and);
+		} else {
+			atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
+			atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
+		}
+	}
+	__syncthreads();
+	const K vary = s_or[0] ^ s_or[1];
+	__syncthreads();
+
+	bool in_lds = false;
+	for (uint32_t shift = 0; shift < sg.bits; shift += 8) {
+		const uint32_t width = sg.bits - shift < 8 ? sg.bits - shift : 8;
+		const uint32_t mask = (1u << width) - 1u;
+		if (((uint32_t)(vary >> shift) & mask) == 0) continue; // digit constant over the segment
+		for (uint32_t j = tid; j < NW * kP; j += TH) wcnt[j] = 0;
+		__syncthreads();
+		uint32_t rk[KPT];
+		uint32_t *mycnt = wcnt + w * kP;
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			const uint32_t d = digit_of(kr[i], shift, mask);
+			uint64_t peers = ~0ull;
+#pragma unroll
+			for (int b = 0; b < 8; ++b) {
+				const bool bit = (d >> b) & 1u;
+				const uint64_t m = __ballot(bit);
+				peers &= bit ? m : ~m;
+			}
+			const uint32_t below = __popcll(peers & lt_mask);
+			const int leader = __ffsll((long long)peers) - 1;
+			uint32_t old = 0;
+			if ((int)lane == leader) {
+				old = mycnt[d];
+				mycnt[d] = old + __popcll(peers);
+			}
+			old = __shfl(old, leader);
+			rk[i] = (old + below) | (d << 24); // rank < 2^24
+		}
+		__syncthreads();
+		// exclusive offsets: digit-major, wave-minor
+		uint32_t tot_d = 0;
+		if (tid < kP) {
+#pragma unroll
+			for (int ww = 0; ww < NW; ++ww) {
+				const uint32_t t = wcnt[ww * kP + tid];
+				wcnt[ww * kP + tid] = tot_d;
+				tot_d += t;
+			}
+		}
+		uint32_t gt;
+		const uint32_t ex = block_excl_scan256(tot_d, tmp, gt);
+		if (tid < kP) dbase[tid] = ex;
+		__syncthreads();
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			const uint32_t d = rk[i] >> 24;
+			const uint32_t p = dbase[d] + mycnt[d] + (rk[i] & 0xFFFFFFu);
+			xk[p] = kr[i];
+			if constexpr (HV) xv[p] = vr[i];
+		}
+		__syncthreads();
+		in_lds = true;
+		// is there another pass with a varying digit?
+		bool more = false;
+		for (uint32_t s2 = shift + 8; s2 < sg.bits; s2 += 8) {
+			const uint32_t w2 = sg.bits - s2 < 8 ? sg.bits - s2 : 8;
+			if (((uint32_t)(vary >> s2) & ((1u << w2) - 1u)) != 0) more = true;
+		}
+		if (!more) break;
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			kr[i] = xk[wbase + i * 64 + lane];
+			if constexpr (HV) vr[i] = xv[wbase + i * 64 + lane];
+		}
+		__syncthreads();
+		in_lds = false;
+	}
+	if (in_lds) {
+		for (uint32_t idx = tid; idx < n; idx += TH) {
+			keys[sg.start + idx] = xk[idx];
+			if constexpr (HV) vals[sg.start + idx] = xv[idx];
+		}
+	}
+	// (no varying digit at all: the segment is constant on the bits in question, nothing to do)
+}
+
+template <typename K, typename V> struct SortLds {
+	using C = Cfg<K, V>;
+	static constexpr int CAP = C::SORT_TH * C::SORT_KPT;
+	static constexpr size_t bytes = (size_t)CAP * sizeof(K) + (has_val<V>::value ? (size_t)CAP * 8 : 0) +
+					(size_t)((C::SORT_TH / 64) * kP + kP + 8) * 4 + 16;
+};
+
+// ------------------------------------------------------------- histogram
+
+template <typename K>
+__global__ __launch_bounds__(256) void histogram_kernel(const K *__restrict__ keys, uint64_t n,
+	uint32_t shift, uint32_t radix_bits, unsigned long long *__restrict__ count)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t *h = reinterpret_cast<uint32_t *>(smem);
+	const uint32_t parts = 1u << radix_bits, mask = parts - 1u;
+	for (uint32_t j = threadIdx.x; j < parts; j += 256) h[j] = 0;
+	__syncthreads();
+	constexpr int VEC = Vec16<K>::N;
+	const uint64_t nvec = n / VEC;
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += stride) {
+		if constexpr (sizeof(K) == 4) {
+			const uint4 q = reinterpret_cast<const uint4 *>(keys)[v];
+			atomicAdd(&h[(q.x >> shift) & mask], 1u);
+			atomicAdd(&h[(q.y >> shift) & mask], 1u);
+			atomicAdd(&h[(q.z >> shift) & mask], 1u);
+			atomicAdd(&h[(q.w >> shift) & mask], 1u);
+		} else {
+			const ulonglong2 q = reinterpret_cast<const ulonglong2 *>(keys)[v];
+			atomicAdd(&h[(uint32_t)(q.x >> shift) & mask], 1u);
+			atomicAdd(&h[(uint32_t)(q.y >> shift) & mask], 1u);
+		}
+	}
+	if (blockIdx.x == 0)
+		for (uint64_t i = nvec * VEC + threadIdx.x; i < n; i += 256)
+			atomicAdd(&h[(uint32_t)(keys[i] >> shift) & mask], 1u);
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < parts; j += 256)
+		if (h[j]) atomicAdd(&count[j], (unsigned long long)h[j]);
+}
+
+// ------------------------------------ device-wide scan (decoupled look-back)
+
+constexpr int kScanTh = 256, kScanIpt = 8, kScanTile = kScanTh * kScanIpt;
+constexpr uint64_t kFlagAgg = 1ull << 62, kFlagPre = 2ull << 62, kFlagMask = 3ull << 62;
+
+// tile_state[ntiles] and tile_counter[1] must be zero on entry.
+__global__ __launch_bounds__(kScanTh) void scan_lookback_kernel(const uint64_t *__restrict__ in,
+	uint64_t *__restrict__ out, uint64_t n, unsigned long long *__restrict__ tile_state,
+	uint32_t *__restrict__ tile_counter, uint32_t *__restrict__ err)
+{
+	__shared__ uint64_t tmp[8];
+	__shared__ uint32_t s_tile;
+	__shared__ uint64_t s_prefix;
+	const uint32_t tid = threadIdx.x;
+	if (tid == 0) s_tile = atomicAdd(tile_counter, 1u); // dynamic id: predecessors have started
+	__syncthreads();
+	const uint32_t tile = s_tile;
+	const uint64_t base = (uint64_t)tile * kScanTile + (uint64_t)tid * kScanIpt;
+	uint64_t v[kScanIpt], sum = 0;
+#pragma unroll
+	for (int i = 0; i < kScanIpt; ++i) {
+		v[i] = base + i < n ? in[base + i] : 0;
+		sum += v[i];
+	}
+	// block scan of the per-thread sums (256 threads)
+	uint64_t agg;
+	const uint64_t tex = block_excl_scan256_64(sum, tmp, agg);
+	if (tid == 0) {
+		uint64_t prefix = 0;
+		if (tile == 0) {
+			__hip_atomic_store(&tile_state[0], kFlagPre | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			__hip_atomic_store(&tile_state[tile], kFlagAgg | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			uint32_t t = tile - 1;
+			uint32_t spins = 0;
+			for (;;) {
+				const uint64_t s = __hip_atomic_load(&tile_state[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint64_t f = s & kFlagMask;
+				if (f == 0) {
+					if (++spins > (1u << 26)) { // bounded: report instead of hanging
+						atomicAdd(err, 1u);
+						break;
+					}
+					__builtin_amdgcn_s_sleep(1);
+					continue;
+				}
+				prefix += s & ~kFlagMask;
+				if (f == kFlagPre) break;
+				--t;
+			}
+			__hip_atomic_store(&tile_state[tile], kFlagPre | (prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		s_prefix = prefix;
+	}
+	__syncthreads();
+	uint64_t run = s_prefix + tex;
+#pragma unroll
+	for (int i = 0; i < kScanIpt; ++i) {
+		if (base + i < n) out[base + i] = run;
+		run += v[i];
+	}
+}
+
+// ------------------------------------------------------------- verifier
+
+struct CheckResult {
+	unsigned long long violations, sum, xr;
+};
+
+template <typename K>
+__global__ __launch_bounds__(256) void check_kernel(const K *__restrict__ keys, const uint64_t *__restrict__ rids,
+	uint64_t n, CheckResult *__restrict__ res)
+{
+	unsigned long long bad = 0, sum = 0, xr = 0;
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+		const K k = keys[i];
+		if (i > 0 && k < keys[i - 1]) ++bad;
+		if (rids && rids[i] != (uint64_t)k) ++bad;
+		sum += (unsigned long long)k;
+		xr ^= (unsigned long long)k;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		bad += __shfl_xor(bad, o);
+		sum += __shfl_xor(sum, o);
+		xr ^= __shfl_xor(xr, o);
+	}
+	if (lane_id() == 0) {
+		if (bad) atomicAdd(&res->violations, bad);
+		atomicAdd(&res->sum, sum);
+		atomicXor(&res->xr, xr);
+	}
+}
+
+// ------------------------------------------------------------- generators
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x)
+{
+	x += 0x9E3779B97F4A7C15ull;
+	uint64_t z = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+	z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+	return z ^ (z >> 31);
+}
+
+__global__ void gen_uniform_u32_kernel(uint32_t *out, uint64_t n, uint64_t seed)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		out[i] = (uint32_t)(splitmix64(seed + i) >> 32);
+}
+__global__ void gen_uniform_u64_kernel(uint64_t *out, uint64_t n, uint64_t seed, int shr)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		out[i] = splitmix64(seed + i) >> shr;
+}
+__global__ void gen_zipf_u32_kernel(uint32_t *out, uint64_t n, uint64_t seed)
+{
+	const double U = 4294967296.0;
+	const double lnU1 = log(U + 1.0);
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+		const double u = (double)(splitmix64(seed + i) >> 11) * 0x1.0p-53;
+		double r = floor(exp(u * lnU1));
+		r = r < 1.0 ? 1.0 : (r > U ? U : r);
+		out[i] = (uint32_t)((uint64_t)r - 1);
+	}
+}
+__global__ void gen_iota_u64_kernel(uint64_t *out, uint64_t n, uint64_t first)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		out[i] = first + i;
+}
+
+} // namespace msd

@@ -1,0 +1,799 @@
+// msd_radix.hip -- host side of the MI355X in-place MSD radix sort and its C ABI
+// (include/msd_radix_hip.h).  The host plans rounds (the role of the reference's
+// schedule_passes, src/msb_64.c:1334-1400, re-parameterised for LDS capacity and
+// <= 8-bit digits) and launches the kernels of msd_device.hpp; it never touches
+// key data itself and has no CPU fallback.
+#include "msd_device.hpp"
+#include "../../include/msd_radix_hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace msd;
+
+#define MSD_VERSION "inplacemsdradixsort_amd 0.1 (gfx950)"
+
+struct PhaseRec {
+	const char *name;
+	hipEvent_t ev; // recorded at the END of the phase
+};
+
+struct msd_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	char *slab = nullptr; // device workspace of the current round (dead between rounds)
+	size_t slab_bytes = 0;
+	char *keep = nullptr; // device workspace that lives for the whole call
+	size_t keep_bytes = 0;
+	void *pinned = nullptr; // small host staging (pinned)
+	size_t pinned_bytes = 0;
+	std::string err;
+	bool profiling = false;
+	hipEvent_t ev_start = nullptr;
+	std::vector<PhaseRec> phases;
+	std::vector<hipEvent_t> ev_pool;
+	size_t ev_used = 0;
+	std::vector<std::pair<std::string, double>> phase_us;
+	std::vector<std::pair<std::string, uint64_t>> stats;
+	int sm_count = 256;
+};
+
+static int fail(msd_ctx *c, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (c) c->err = buf;
+	return code;
+}
+
+#define HIPCHK(c, call)                                                                   \
+	do {                                                                              \
+		hipError_t e_ = (call);                                                   \
+		if (e_ != hipSuccess)                                                     \
+			return fail(c, MSD_EHIP, "%s failed: %s (%s:%d)", #call,          \
+				    hipGetErrorString(e_), __FILE__, __LINE__);           \
+	} while (0)
+
+static void set_stat(msd_ctx *c, const char *name, uint64_t v)
+{
+	for (auto &s : c->stats)
+		if (s.first == name) {
+			s.second = v;
+			return;
+		}
+	c->stats.emplace_back(name, v);
+}
+static void add_stat(msd_ctx *c, const char *name, uint64_t v)
+{
+	for (auto &s : c->stats)
+		if (s.first == name) {
+			s.second += v;
+			return;
+		}
+	c->stats.emplace_back(name, v);
+}
+
+// ------------------------------------------------------------ workspace slab
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int dev_reserve(msd_ctx *c, char *&p, size_t &have, size_t bytes)
+{
+	if (bytes <= have) return MSD_OK;
+	if (p) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipFree(p));
+		p = nullptr;
+		have = 0;
+	}
+	bytes = align_up(bytes + bytes / 8, 1 << 20);
+	hipError_t e = hipMalloc((void **)&p, bytes);
+	if (e != hipSuccess) return fail(c, MSD_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+	have = bytes;
+	return MSD_OK;
+}
+static int slab_reserve(msd_ctx *c, size_t bytes) { return dev_reserve(c, c->slab, c->slab_bytes, bytes); }
+static int keep_reserve(msd_ctx *c, size_t bytes) { return dev_reserve(c, c->keep, c->keep_bytes, bytes); }
+
+struct Bump { // sizing pass (base == nullptr) or carving pass
+	char *base;
+	size_t off = 0;
+	explicit Bump(char *b) : base(b) {}
+	template <typename T> T *take(size_t n)
+	{
+		off = align_up(off, 256);
+		T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+		off += n * sizeof(T);
+		return p;
+	}
+};
+
+static int pinned_reserve(msd_ctx *c, size_t bytes)
+{
+	if (bytes <= c->pinned_bytes) return MSD_OK;
+	if (c->pinned) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		HIPCHK(c, hipHostFree(c->pinned));
+		c->pinned = nullptr;
+	}
+	bytes = align_up(bytes * 2, 4096);
+	HIPCHK(c, hipHostMalloc(&c->pinned, bytes, hipHostMallocDefault));
+	c->pinned_bytes = bytes;
+	return MSD_OK;
+}
+
+// ------------------------------------------------------------ phase timing
+
+static void phase_begin(msd_ctx *c)
+{
+	c->phases.clear();
+	c->ev_used = 0;
+	c->phase_us.clear();
+	if (!c->profiling) return;
+	if (!c->ev_start) (void)hipEventCreate(&c->ev_start);
+	(void)hipEventRecord(c->ev_start, c->stream);
+}
+static void phase_mark(msd_ctx *c, const char *name)
+{
+	if (!c->profiling) return;
+	if (c->ev_used == c->ev_pool.size()) {
+		hipEvent_t e;
+		(void)hipEventCreate(&e);
+		c->ev_pool.push_back(e);
+	}
+	hipEvent_t e = c->ev_pool[c->ev_used++];
+	(void)hipEventRecord(e, c->stream);
+	c->phases.push_back({ name, e });
+}
+static void phase_end(msd_ctx *c)
+{
+	if (!c->profiling) return;
+	(void)hipStreamSynchronize(c->stream);
+	hipEvent_t prev = c->ev_start;
+	for (auto &p : c->phases) {
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, prev, p.ev);
+		bool found = false;
+		for (auto &q : c->phase_us)
+			if (q.first == p.name) {
+				q.second += ms * 1000.0;
+				found = true;
+			}
+		if (!found) c->phase_us.emplace_back(p.name, ms * 1000.0);
+		prev = p.ev;
+	}
+}
+
+// ------------------------------------------------------------ round planning
+
+template <typename K, typename V> struct Elem {
+	static constexpr size_t key = sizeof(K);
+	static constexpr size_t val = has_val<V>::value ? 8 : 0;
+};
+
+struct RoundPlan {
+	std::vector<Parent> parents;
+	std::vector<Stripe> stripes;
+	uint32_t nchildren = 0;
+	uint64_t lo_elems = 0;   // leftover area, elements
+	uint64_t nslots = 0;     // slots covered by the stripes
+	uint64_t round_keys = 0;
+};
+
+static uint32_t ceil_log2_u64(uint64_t x)
+{
+	uint32_t p = 0;
+	while (((uint64_t)1 << p) < x) ++p;
+	return p;
+}
+
+// Digit width for a parent: 8 bits for big parents, fewer when that already
+// brings the children down to about half the LDS-sort capacity.
+static uint32_t pick_width(uint64_t count, uint32_t bits, uint64_t small_max)
+{
+	uint64_t target = small_max / 2;
+	uint32_t w = ceil_log2_u64((count + target - 1) / target);
+	w = std::max(1u, std::min(8u, w));
+	return std::min(w, bits);
+}
+
+template <typename K, typename V>
+static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int sm_count, RoundPlan &rp)
+{
+	using C = Cfg<K, V>;
+	constexpr uint64_t B = C::B, T = C::T;
+	rp = RoundPlan();
+	uint64_t total = 0;
+	for (auto &s : segs) total += s.count;
+	rp.round_keys = total;
+	// stripe length: enough stripes to fill the chip a few times over, whole tiles
+	uint64_t want = std::max<uint64_t>(1, (uint64_t)sm_count * 4);
+	uint64_t slen = (total + want - 1) / want;
+	slen = std::max<uint64_t>(slen, 4 * T);
+	slen = std::min<uint64_t>(slen, (uint64_t)1 << 20);
+	slen = (slen + T - 1) / T * T;
+	for (auto &s : segs) {
+		Parent p;
+		p.start = s.start;
+		p.count = s.count;
+		p.width = pick_width(s.count, s.bits, small_max);
+		p.shift = s.bits - p.width;
+		p.child_base = rp.nchildren;
+		p.stripe_lo = (uint32_t)rp.stripes.size();
+		p.pad = 0;
+		rp.nchildren += 1u << p.width;
+		const uint64_t end = s.start + s.count;
+		const uint64_t a0 = (s.start + B - 1) / B * B; // first aligned position
+		uint64_t b = s.start;
+		while (b < end) {
+			uint64_t e = (b == s.start ? a0 : b) + slen;
+			if (e + slen / 2 > end) e = end; // do not leave a short last stripe
+			Stripe st;
+			st.begin = b;
+			st.end = e;
+			st.parent = (uint32_t)rp.parents.size();
+			st.slot_lo = (uint32_t)((b + B - 1) / B);
+			st.slot_hi = (uint32_t)(e / B);
+			if (st.slot_hi < st.slot_lo) st.slot_hi = st.slot_lo;
+			st.lo_base = rp.lo_elems;
+			st.pad = 0;
+			// leftovers: < B per bucket from the stream, plus < B head keys
+			rp.lo_elems += std::min<uint64_t>(e - b, (uint64_t)kP * (B - 1) + B);
+			rp.nslots += st.slot_hi - st.slot_lo;
+			rp.stripes.push_back(st);
+			b = e;
+		}
+		p.stripe_hi = (uint32_t)rp.stripes.size();
+		rp.parents.push_back(p);
+	}
+}
+
+struct RoundBufs {
+	Parent *parents;
+	Stripe *stripes;
+	uint32_t *fb, *lo_cnt, *lo_off, *lo_dst, *nfull;
+	void *lo_keys;
+	uint64_t *lo_vals;
+	ChildArrays ca;
+	ListEntry *list, *holes;
+	void *xkeys;
+	uint64_t *xvals;
+	unsigned long long *scan_state;
+	uint32_t *scan_ctr;
+	Segment *next_parents;
+};
+
+template <typename K, typename V>
+static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundBufs &rb)
+{
+	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
+	const size_t np = rp.parents.size(), ns = rp.stripes.size(), nc = rp.nchildren;
+	rb.parents = b.take<Parent>(np);
+	rb.stripes = b.take<Stripe>(ns);
+	rb.fb = b.take<uint32_t>(ns * kP);
+	rb.lo_cnt = b.take<uint32_t>(ns * kP);
+	rb.lo_off = b.take<uint32_t>(ns * kP);
+	rb.lo_dst = b.take<uint32_t>(ns * kP);
+	rb.nfull = b.take<uint32_t>(ns);
+	rb.lo_keys = b.take<K>(rp.lo_elems);
+	rb.lo_vals = HV ? b.take<uint64_t>(rp.lo_elems) : nullptr;
+	rb.ca.start = b.take<uint64_t>(nc);
+	rb.ca.count = b.take<uint64_t>(nc);
+	rb.ca.F = b.take<uint32_t>(nc);
+	rb.ca.is = b.take<uint32_t>(nc);
+	rb.ca.I = b.take<uint32_t>(nc);
+	rb.ca.lsum = b.take<uint32_t>(nc);
+	rb.ca.n_int = b.take<uint32_t>(nc);
+	rb.ca.n_fr = b.take<uint32_t>(nc);
+	rb.ca.n_int0 = b.take<uint32_t>(nc);
+	rb.ca.cur_int = b.take<uint32_t>(nc);
+	rb.ca.cur_fr = b.take<uint32_t>(nc);
+	rb.ca.list_len = b.take<uint64_t>(nc);
+	rb.ca.list_base = b.take<uint64_t>(nc);
+	rb.ca.rpos = b.take<uint32_t>(nc);
+	rb.ca.flags = b.take<uint32_t>(nc);
+	rb.list = b.take<ListEntry>(rp.nslots + 1);
+	// holes: tail slots (< kP + 2 per stripe) + one eviction + one excess per child
+	const uint64_t hmax = std::min<uint64_t>(rp.nslots, (uint64_t)ns * (kP + 2)) + 2ull * nc + 1;
+	rb.holes = b.take<ListEntry>(hmax);
+	rb.xkeys = b.take<K>((size_t)2 * nc * C::B);
+	rb.xvals = HV ? b.take<uint64_t>((size_t)2 * nc * C::B) : nullptr;
+	const size_t ntiles = (nc + kScanTile - 1) / kScanTile + 1;
+	rb.scan_state = b.take<unsigned long long>(ntiles);
+	rb.scan_ctr = b.take<uint32_t>(4);
+	// children that stay big: each has > small_max elements
+	rb.next_parents = b.take<Segment>(rp.round_keys / (small_max + 1) + 2);
+}
+
+// scan helper on the context stream
+static int run_scan(msd_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n,
+		    unsigned long long *state, uint32_t *ctr, uint32_t *err)
+{
+	if (n == 0) return MSD_OK;
+	const size_t ntiles = (n + kScanTile - 1) / kScanTile;
+	HIPCHK(c, hipMemsetAsync(state, 0, ntiles * sizeof(unsigned long long), c->stream));
+	HIPCHK(c, hipMemsetAsync(ctr, 0, 16, c->stream));
+	hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)ntiles), dim3(kScanTh), 0, c->stream, in, out, n, state, ctr, err);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
+// ------------------------------------------------------------------ the sort
+
+template <typename K, typename V> static uint64_t small_list_cap(uint64_t n)
+{
+	using C = Cfg<K, V>;
+	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
+	// children per round <= 6 n / small_max (pick_width); allow 2 rounds per key byte
+	const uint64_t cap = (uint64_t)(2 * sizeof(K)) * (6 * n / small_max + 512) + 16;
+	return std::min<uint64_t>(cap, n / 2 + 16);
+}
+
+template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
+{
+	Bump b(nullptr);
+	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
+	b.take<Counters>(1);
+	b.take<Segment>(small_list_cap<K, V>(n));
+	return b.off + 4096;
+}
+
+// Per-round workspace for the two shapes the headline sizes produce: one parent
+// covering everything, and 256 equal parents.  Other shapes grow the slab between
+// rounds (nothing in it is live there).
+template <typename K, typename V>
+static size_t round_bytes_estimate(uint64_t n, int sm_count)
+{
+	using C = Cfg<K, V>;
+	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
+	size_t worst = 0;
+	for (int shape = 0; shape < 2; ++shape) {
+		std::vector<Segment> segs;
+		if (shape == 0)
+			segs.push_back({ 0, n, (uint32_t)(sizeof(K) * 8), 0 });
+		else if (n > 512 * small_max)
+			for (int i = 0; i < 256; ++i) segs.push_back({ n / 256 * i, n / 256, (uint32_t)(sizeof(K) * 8 - 8), 0 });
+		if (segs.empty()) continue;
+		RoundPlan rp;
+		plan_round<K, V>(segs, small_max, sm_count, rp);
+		Bump b(nullptr);
+		RoundBufs rb;
+		carve_round<K, V>(b, rp, small_max, rb);
+		worst = std::max(worst, b.off);
+	}
+	return worst + 4096;
+}
+
+template <typename K, typename V>
+static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bit,
+		     // single-pass mode (msd_partition_*): one round, caller-chosen digit
+		     bool single_pass, unsigned sp_shift, unsigned sp_width, uint64_t *sp_count)
+{
+	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
+	constexpr int B = C::B;
+	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
+	if (n == 0) return MSD_OK;
+	if (!keys || (HV && !vals)) return fail(c, MSD_EINVAL, "null data pointer");
+	if (((uintptr_t)keys & 15) || (HV && ((uintptr_t)vals & 15)))
+		return fail(c, MSD_EINVAL, "keys/rids must be 16-byte aligned (the reference asserts the same, src/msb_64.c:2273)");
+	if (end_bit < 0 || end_bit > (int)sizeof(K) * 8) return fail(c, MSD_EINVAL, "end_bit out of range");
+	if (n >= ((uint64_t)1 << 36)) return fail(c, MSD_EINVAL, "n too large for 32-bit block slots");
+	HIPCHK(c, hipSetDevice(c->device));
+	c->stats.clear();
+	phase_begin(c);
+
+	std::vector<Segment> cur;
+	if (single_pass) {
+		if (sp_width < 1 || sp_width > 8 || sp_shift + sp_width > sizeof(K) * 8)
+			return fail(c, MSD_EINVAL, "partition: radix_bits must be 1..8 and shift+radix_bits within the key");
+		cur.push_back({ 0, n, sp_shift + sp_width, 0 });
+	} else if (end_bit > 0 && n > 1)
+		cur.push_back({ 0, n, (uint32_t)end_bit, 0 });
+
+	// ---- buffers that live for the whole call
+	const uint64_t small_cap = small_list_cap<K, V>(n);
+	{
+		int rc = keep_reserve(c, keep_bytes_for<K, V>(n));
+		if (!rc) rc = pinned_reserve(c, 1 << 16);
+		if (rc) return rc;
+	}
+	Bump kb(c->keep);
+	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
+	Counters *ctr = kb.take<Counters>(1);
+	Segment *small = kb.take<Segment>(small_cap);
+	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
+
+	uint32_t nsmall_host = 0;
+	if (!single_pass && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		memcpy(c->pinned, &cur[0], sizeof(Segment));
+		HIPCHK(c, hipMemcpyAsync(small, c->pinned, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+		nsmall_host = 1;
+		cur.clear();
+	}
+
+	int round = 0;
+	while (!cur.empty()) {
+		RoundPlan rp;
+		plan_round<K, V>(cur, small_max, c->sm_count, rp);
+		if (single_pass) { // honour the caller's digit exactly
+			rp.parents[0].width = sp_width;
+			rp.parents[0].shift = sp_shift;
+			rp.nchildren = 1u << sp_width;
+		}
+		RoundBufs rb;
+		{
+			Bump sz(nullptr);
+			carve_round<K, V>(sz, rp, small_max, rb);
+			size_t need = sz.off + 4096;
+			if (round == 0 && !single_pass) need = std::max(need, round_bytes_estimate<K, V>(n, c->sm_count));
+			int rc = slab_reserve(c, need); // between rounds nothing in the slab is live
+			if (rc) return rc;
+			Bump b(c->slab);
+			carve_round<K, V>(b, rp, small_max, rb);
+		}
+		const uint32_t np = (uint32_t)rp.parents.size(), ns = (uint32_t)rp.stripes.size(), nc = rp.nchildren;
+		if (round > 0) HIPCHK(c, hipMemsetAsync(ctr, 0, 3 * sizeof(uint32_t), c->stream)); // nholes, hole_cursor, next_parents
+		// ---- upload tables
+		{
+			const size_t bytes = np * sizeof(Parent) + ns * sizeof(Stripe);
+			int rc = pinned_reserve(c, bytes);
+			if (rc) return rc;
+			HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
+			memcpy(c->pinned, rp.parents.data(), np * sizeof(Parent));
+			memcpy((char *)c->pinned + np * sizeof(Parent), rp.stripes.data(), ns * sizeof(Stripe));
+			HIPCHK(c, hipMemcpyAsync(rb.parents, c->pinned, np * sizeof(Parent), hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, hipMemcpyAsync(rb.stripes, (char *)c->pinned + np * sizeof(Parent), ns * sizeof(Stripe), hipMemcpyHostToDevice, c->stream));
+		}
+		phase_mark(c, "plan+upload");
+
+		// ---- A: classify (histogram falls out of it)
+		constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
+		hipLaunchKernelGGL((classify_kernel<K, V>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
+				   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+				   (K *)rb.lo_keys, rb.lo_vals, rb.nfull);
+		HIPCHK(c, hipGetLastError());
+		phase_mark(c, "A classify");
+
+		// ---- block metadata: child geometry, misplaced-block lists, holes
+		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(256), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
+		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
+				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr);
+		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca);
+		{
+			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors);
+			if (rc) return rc;
+		}
+		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
+				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr);
+		hipLaunchKernelGGL((evict_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
+				   keys, vals, (K *)rb.xkeys, rb.xvals);
+		HIPCHK(c, hipGetLastError());
+		phase_mark(c, "B metadata");
+
+		// ---- B: block permutation
+		{
+			const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, std::max<uint64_t>(1, (rp.nslots + 255) / 256));
+			hipLaunchKernelGGL((chains_kernel<K, V>), dim3(grid), dim3(256), 0, c->stream, rb.ca, rb.list, rb.holes, ctr,
+					   keys, vals, (K *)rb.xkeys, rb.xvals);
+			hipLaunchKernelGGL(chains_verify_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr);
+			HIPCHK(c, hipGetLastError());
+		}
+		phase_mark(c, "B block permute");
+
+		// ---- C: cleanup
+		hipLaunchKernelGGL((cleanup_kernel<K, V>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents, rb.lo_cnt,
+				   rb.lo_off, rb.lo_dst, rb.ca, (const K *)rb.lo_keys, rb.lo_vals, keys, vals);
+		hipLaunchKernelGGL((excess_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, (const K *)rb.xkeys, rb.xvals, keys, vals);
+		hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, rb.parents, rb.ca,
+				   single_pass ? ~0ull : small_max, (uint32_t)small_cap, rb.next_parents, small, ctr,
+				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr);
+		HIPCHK(c, hipGetLastError());
+		phase_mark(c, "C cleanup");
+
+		// ---- round summary + next parents back to the host (which plans the next round)
+		Counters hc;
+		HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		memcpy(&hc, c->pinned, sizeof hc);
+		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations", round, hc.errors);
+		nsmall_host = hc.nsmall;
+		add_stat(c, "rounds", 1);
+		add_stat(c, "parents", np);
+		add_stat(c, "stripes", ns);
+		add_stat(c, "children", nc);
+		add_stat(c, "slots", rp.nslots);
+		add_stat(c, "holes", hc.nholes);
+		set_stat(c, "chain_steps", hc.chain_steps);
+		cur.clear();
+		if (single_pass) break;
+		if (hc.next_parents) {
+			int rc = pinned_reserve(c, (size_t)hc.next_parents * sizeof(Segment));
+			if (rc) return rc;
+			HIPCHK(c, hipMemcpyAsync(c->pinned, rb.next_parents, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			cur.assign((Segment *)c->pinned, (Segment *)c->pinned + hc.next_parents);
+			// atomic appends arrive in any order; make the plan deterministic
+			std::sort(cur.begin(), cur.end(), [](const Segment &a, const Segment &b) { return a.start < b.start; });
+		}
+		phase_mark(c, "readback");
+		++round;
+	}
+
+	// ---- segments that fit LDS are finished there
+	if (nsmall_host && !single_pass) {
+		constexpr size_t sort_lds = SortLds<K, V>::bytes;
+		hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), sort_lds, c->stream,
+				   keys, vals, small, nsmall_host);
+		HIPCHK(c, hipGetLastError());
+		phase_mark(c, "LDS sort");
+	}
+	set_stat(c, "small_segments", nsmall_host);
+	set_stat(c, "workspace_bytes", c->slab_bytes + c->keep_bytes);
+	phase_end(c);
+	return MSD_OK;
+}
+
+template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
+{
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_kernel<K, V>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
+	return MSD_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+const char *msd_version(void) { return MSD_VERSION; }
+
+int msd_create(msd_ctx **out, int device, void *stream)
+{
+	if (!out) return MSD_EINVAL;
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return MSD_EHIP; // no CPU fallback exists
+	if (device < 0 || device >= ndev) return MSD_EINVAL;
+	msd_ctx *c = new msd_ctx();
+	c->device = device;
+	c->stream = (hipStream_t)stream;
+	if (hipSetDevice(device) != hipSuccess) {
+		delete c;
+		return MSD_EHIP;
+	}
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->sm_count = prop.multiProcessorCount;
+	int rc = set_lds_attrs<uint32_t, NoVal>(c);
+	if (!rc) rc = set_lds_attrs<uint64_t, NoVal>(c);
+	if (!rc) rc = set_lds_attrs<uint64_t, uint64_t>(c);
+	if (rc) {
+		fprintf(stderr, "msd_create: %s\n", c->err.c_str());
+		delete c;
+		return rc;
+	}
+	*out = c;
+	return MSD_OK;
+}
+
+int msd_destroy(msd_ctx *c)
+{
+	if (!c) return MSD_EINVAL;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamSynchronize(c->stream);
+	if (c->slab) (void)hipFree(c->slab);
+	if (c->keep) (void)hipFree(c->keep);
+	if (c->pinned) (void)hipHostFree(c->pinned);
+	if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+	delete c;
+	return MSD_OK;
+}
+
+int msd_set_stream(msd_ctx *c, void *stream)
+{
+	if (!c) return MSD_EINVAL;
+	c->stream = (hipStream_t)stream;
+	return MSD_OK;
+}
+
+int msd_reserve(msd_ctx *c, uint64_t n, int key_bytes, int val_bytes)
+{
+	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	size_t round_b, keep_b;
+	if (key_bytes == 4 && val_bytes == 0) {
+		round_b = round_bytes_estimate<uint32_t, NoVal>(n, c->sm_count);
+		keep_b = keep_bytes_for<uint32_t, NoVal>(n);
+	} else if (key_bytes == 8 && val_bytes == 0) {
+		round_b = round_bytes_estimate<uint64_t, NoVal>(n, c->sm_count);
+		keep_b = keep_bytes_for<uint64_t, NoVal>(n);
+	} else if (key_bytes == 8 && val_bytes == 8) {
+		round_b = round_bytes_estimate<uint64_t, uint64_t>(n, c->sm_count);
+		keep_b = keep_bytes_for<uint64_t, uint64_t>(n);
+	} else
+		return fail(c, MSD_EINVAL, "unsupported element layout %d+%d bytes", key_bytes, val_bytes);
+	int rc = slab_reserve(c, round_b);
+	if (!rc) rc = keep_reserve(c, keep_b);
+	if (!rc) rc = pinned_reserve(c, 1 << 20);
+	return rc;
+}
+
+uint64_t msd_workspace_bytes(const msd_ctx *c) { return c ? c->slab_bytes + c->keep_bytes : 0; }
+const char *msd_last_error(const msd_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int msd_sort_u32_bits(msd_ctx *c, uint32_t *k, uint64_t n, int end_bit)
+{
+	if (!c) return MSD_EINVAL;
+	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, end_bit, false, 0, 0, nullptr);
+}
+int msd_sort_u64_bits(msd_ctx *c, uint64_t *k, uint64_t n, int end_bit)
+{
+	if (!c) return MSD_EINVAL;
+	return sort_impl<uint64_t, NoVal>(c, k, nullptr, n, end_bit, false, 0, 0, nullptr);
+}
+int msd_sort_pairs_u64_bits(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, int end_bit)
+{
+	if (!c) return MSD_EINVAL;
+	return sort_impl<uint64_t, uint64_t>(c, k, r, n, end_bit, false, 0, 0, nullptr);
+}
+int msd_sort_u32(msd_ctx *c, uint32_t *k, uint64_t n) { return msd_sort_u32_bits(c, k, n, 32); }
+int msd_sort_u64(msd_ctx *c, uint64_t *k, uint64_t n) { return msd_sort_u64_bits(c, k, n, 64); }
+int msd_sort_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n) { return msd_sort_pairs_u64_bits(c, k, r, n, 64); }
+
+int msd_partition_u32(msd_ctx *c, uint32_t *k, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
+{
+	if (!c) return MSD_EINVAL;
+	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
+	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, 32, true, shift, rb, cnt);
+}
+int msd_partition_u64(msd_ctx *c, uint64_t *k, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
+{
+	if (!c) return MSD_EINVAL;
+	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
+	return sort_impl<uint64_t, NoVal>(c, k, nullptr, n, 64, true, shift, rb, cnt);
+}
+int msd_partition_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
+{
+	if (!c) return MSD_EINVAL;
+	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
+	return sort_impl<uint64_t, uint64_t>(c, k, r, n, 64, true, shift, rb, cnt);
+}
+
+} // extern "C"
+
+template <typename K>
+static int histogram_impl(msd_ctx *c, const K *k, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
+{
+	if (!c) return MSD_EINVAL;
+	if (!cnt || (n && !k)) return fail(c, MSD_EINVAL, "null pointer");
+	if (rb < 1 || rb > 12 || shift + rb > sizeof(K) * 8) return fail(c, MSD_EINVAL, "radix_bits must be 1..12 and shift+radix_bits within the key");
+	if ((uintptr_t)k & 15) return fail(c, MSD_EINVAL, "keys must be 16-byte aligned");
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
+	if (n == 0) return MSD_OK;
+	const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (n + 4095) / 4096);
+	hipLaunchKernelGGL((histogram_kernel<K>), dim3(grid), dim3(256), sizeof(uint32_t) << rb, c->stream, k, n, shift, rb,
+			   (unsigned long long *)cnt);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+extern "C" {
+
+int msd_histogram_u32(msd_ctx *c, const uint32_t *k, uint64_t n, unsigned s, unsigned rb, uint64_t *cnt) { return histogram_impl(c, k, n, s, rb, cnt); }
+int msd_histogram_u64(msd_ctx *c, const uint64_t *k, uint64_t n, unsigned s, unsigned rb, uint64_t *cnt) { return histogram_impl(c, k, n, s, rb, cnt); }
+
+int msd_exclusive_scan_u64(msd_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n)
+{
+	if (!c) return MSD_EINVAL;
+	if (n && (!in || !out)) return fail(c, MSD_EINVAL, "null pointer");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (n == 0) return MSD_OK;
+	const size_t ntiles = (n + kScanTile - 1) / kScanTile;
+	int rc = slab_reserve(c, ntiles * 8 + 4096);
+	if (rc) return rc;
+	unsigned long long *state = (unsigned long long *)(c->slab + 256);
+	uint32_t *ctr = (uint32_t *)c->slab; // [0] tile counter, [2] error flag
+	HIPCHK(c, hipMemsetAsync(c->slab, 0, 256, c->stream));
+	HIPCHK(c, hipMemsetAsync(state, 0, ntiles * 8, c->stream));
+	hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)ntiles), dim3(kScanTh), 0, c->stream, in, out, n, state, ctr, ctr + 2);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
+} // extern "C"
+
+template <typename K>
+static int check_impl(msd_ctx *c, const K *k, const uint64_t *r, uint64_t n, uint64_t *viol, uint64_t *sum, uint64_t *xr)
+{
+	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	int rc = slab_reserve(c, 4096);
+	if (!rc) rc = pinned_reserve(c, 4096);
+	if (rc) return rc;
+	CheckResult *res = (CheckResult *)c->slab;
+	HIPCHK(c, hipMemsetAsync(res, 0, sizeof *res, c->stream));
+	if (n) {
+		const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (n + 255) / 256);
+		hipLaunchKernelGGL((check_kernel<K>), dim3(grid), dim3(256), 0, c->stream, k, r, n, res);
+		HIPCHK(c, hipGetLastError());
+	}
+	HIPCHK(c, hipMemcpyAsync(c->pinned, res, sizeof *res, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	const CheckResult *h = (const CheckResult *)c->pinned;
+	if (viol) *viol = h->violations;
+	if (sum) *sum = h->sum;
+	if (xr) *xr = h->xr;
+	return MSD_OK;
+}
+extern "C" {
+
+int msd_check_u32(msd_ctx *c, const uint32_t *k, uint64_t n, uint64_t *v, uint64_t *s, uint64_t *x) { return check_impl<uint32_t>(c, k, nullptr, n, v, s, x); }
+int msd_check_u64(msd_ctx *c, const uint64_t *k, const uint64_t *r, uint64_t n, uint64_t *v, uint64_t *s, uint64_t *x) { return check_impl<uint64_t>(c, k, r, n, v, s, x); }
+
+static unsigned gen_grid(const msd_ctx *c, uint64_t n) { return (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 16, (n + 255) / 256 + 1); }
+
+int msd_gen_uniform_u32(msd_ctx *c, uint32_t *k, uint64_t n, uint64_t seed, uint64_t first)
+{
+	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL(gen_uniform_u32_kernel, dim3(gen_grid(c, n)), dim3(256), 0, c->stream, k, n, seed + first);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+int msd_gen_uniform_u64(msd_ctx *c, uint64_t *k, uint64_t n, uint64_t seed, uint64_t first, int shr)
+{
+	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL(gen_uniform_u64_kernel, dim3(gen_grid(c, n)), dim3(256), 0, c->stream, k, n, seed + first, shr);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+int msd_gen_zipf_u32(msd_ctx *c, uint32_t *k, uint64_t n, uint64_t seed, uint64_t first)
+{
+	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL(gen_zipf_u32_kernel, dim3(gen_grid(c, n)), dim3(256), 0, c->stream, k, n, seed + first);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+int msd_gen_iota_u64(msd_ctx *c, uint64_t *v, uint64_t n, uint64_t first)
+{
+	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL(gen_iota_u64_kernel, dim3(gen_grid(c, n)), dim3(256), 0, c->stream, v, n, first);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
+int msd_set_profiling(msd_ctx *c, int on)
+{
+	if (!c) return MSD_EINVAL;
+	c->profiling = on != 0;
+	return MSD_OK;
+}
+int msd_phase_count(const msd_ctx *c) { return c ? (int)c->phase_us.size() : 0; }
+const char *msd_phase_name(const msd_ctx *c, int i) { return (c && i >= 0 && i < (int)c->phase_us.size()) ? c->phase_us[i].first.c_str() : ""; }
+double msd_phase_us(const msd_ctx *c, int i) { return (c && i >= 0 && i < (int)c->phase_us.size()) ? c->phase_us[i].second : 0.0; }
+int msd_stat(const msd_ctx *c, const char *name, uint64_t *v)
+{
+	if (!c || !name || !v) return MSD_EINVAL;
+	for (auto &s : c->stats)
+		if (s.first == name) {
+			*v = s.second;
+			return MSD_OK;
+		}
+	return MSD_EINVAL;
+}
+
+} // extern "C"
