@@ -1,0 +1,73 @@
+"""Multi-GPU range partition + one all-to-all.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Rank g
+holds a shard of keys in HBM.  Like the reference's NUMA phase -- contiguous key
+ranges per node (numa_dest, src/msb_64.c:1596-1607), blocks balanced across nodes
+(:1952-1997), then purely local sorting (:2200-2255) -- the distributed sort is:
+
+  1. one in-place top-digit pass on every rank (``engine.partition``): buckets end up
+     contiguous in ascending digit order, so the slice for destination rank d
+     (digits [d*256/G, (d+1)*256/G)) is already packed for sending;
+  2. a G x G count exchange and ONE all-to-all(v) of the keys;
+  3. each rank sorts what it received; all its keys share the top log2(G) bits, which
+     are passed on as ``end_bit`` (the reference passes bits=58 after its 6-bit split,
+     src/msb_64.c:2242).
+
+``engine`` is an :class:`inplacemsdradixsort_amd.MsdContext`; the CPU gloo tests pass a
+stand-in with the same three methods to exercise the exchange logic without a GPU.
+The receive buffer needs slack over n/G under skew (the reference's ``fudge``).
+"""
+from __future__ import annotations
+
+
+def _log2(g: int) -> int:
+    b = g.bit_length() - 1
+    if g < 1 or (1 << b) != g or g > 256:
+        raise ValueError("number of ranks must be a power of two <= 256")
+    return b
+
+
+def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None):
+    """Sorts the union of all ranks' ``keys`` (int32 tensors holding u32 bit patterns).
+    Returns this rank's sorted range as a view of ``recv``; rank r's range precedes rank r+1's."""
+    import torch
+    lg = _log2(world)
+    if world == 1:
+        engine.sort_u32(keys)
+        return keys
+    counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
+    send = counts.view(world, 256 // world).sum(dim=1)           # keys per destination rank
+    got = torch.empty_like(send)
+    dist.all_to_all_single(got, send, group=group)               # count exchange
+    send_l, got_l = send.tolist(), got.tolist()
+    total = int(sum(got_l))
+    if total > recv.numel():
+        raise RuntimeError(f"receive buffer too small: {total} keys for capacity {recv.numel()} "
+                           "(raise the slack, the reference's fudge)")
+    out = recv[:total]
+    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    engine.sort_u32(out, end_bit=32 - lg)
+    return out
+
+
+def splitters_equi_depth(sorted_sample, parts: int):
+    """parts-1 equi-depth delimiters from a sorted sample with the reference's duplicate
+    rule (extract_delimiters, src/msb_64.c:1304-1322): if more repetitions of the picked
+    value lie after the pick than before it, use value-1 so a heavy value does not
+    straddle two ranges.  Range p = keys in (delim[p-1], delim[p]]."""
+    n = len(sorted_sample)
+    out = []
+    pct = n * 1.0 / parts
+    for i in range(parts - 1):
+        idx = int(pct * (i + 1) - 0.001)
+        v = int(sorted_sample[idx])
+        start = idx
+        while start > 0 and int(sorted_sample[start]) == v:
+            start -= 1
+        end = idx
+        while end < n and int(sorted_sample[end]) == v:
+            end += 1
+        if idx - start < end - idx and v:
+            v -= 1
+        out.append(v)
+    return out

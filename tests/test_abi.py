@@ -1,0 +1,62 @@
+"""The C-ABI library loads here (no GPU) and exports every symbol include/*.h
+declares; creating a context without a GPU fails loudly (no CPU fallback)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b([a-z_0-9]+)\s*\(", text)) - {"defined"}
+
+
+def test_every_declared_symbol_is_exported():
+    from inplacemsdradixsort_amd import _lib
+    L = _lib.load()
+    declared = _declared("msd_radix_hip.h") | _declared("msb_64.h")
+    assert {"sort", "mamalloc", "check", "msd_sort_u32", "msd_histogram_u32", "msd_exclusive_scan_u64"} <= declared
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, missing
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert b"gfx950" in L.msd_version()
+
+
+def test_mamalloc_is_64_byte_aligned():
+    from inplacemsdradixsort_amd import _lib
+    L = _lib.load()
+    for sz in (1, 100, 4096, 1 << 20):
+        p = L.mamalloc(sz)
+        assert p and p % 64 == 0  # src/msb_64.c:111-115
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from inplacemsdradixsort_amd import MsdContext, MsdError
+    with pytest.raises(MsdError):
+        MsdContext(0)
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    pkg = os.path.join(ROOT, "inplacemsdradixsort_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                t = open(os.path.join(dp, f)).read()
+                if re.search(r"\boracle\b|liborc|_ref/|msd_oracle", t):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_code_object_is_gfx950_only():
+    from inplacemsdradixsort_amd import LIB
+    data = open(LIB, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx90a", b"gfx942", b"sm_80"):
+        assert other not in data

@@ -1,0 +1,98 @@
+"""world_size-2 and -4 gloo tests (CPU) of the multi-GPU exchange logic: the same
+``sort_sharded_u32`` the GPU bench calls, with a numpy stand-in engine (test
+infrastructure) in place of the HIP context."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+class NumpyEngine:
+    """Stand-in with MsdContext's partition / sort_u32 semantics (tests only)."""
+
+    def partition(self, keys, shift, radix_bits):
+        a = keys.numpy().view(np.uint32)
+        d = (a >> np.uint32(shift)) & np.uint32((1 << radix_bits) - 1)
+        order = np.argsort(d, kind="stable")
+        a[:] = a[order]
+        return torch.from_numpy(np.bincount(d, minlength=1 << radix_bits).astype(np.int64))
+
+    def sort_u32(self, keys, end_bit=32):
+        a = keys.numpy().view(np.uint32)
+        if a.size:
+            assert int((a >> np.uint32(end_bit)).min()) == int((a >> np.uint32(end_bit)).max()) if end_bit < 32 else True
+        a.sort()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, kind, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inplacemsdradixsort_amd.dist import sort_sharded_u32
+    from oracle import oracle as O
+    if kind == "uniform":
+        k = O.gen_uniform_u32(n, first=rank * n)
+    else:
+        k = O.gen_zipf_u32(n, first=rank * n)
+    keys = torch.from_numpy(k.view(np.int32).copy())
+    recv = torch.empty(n * world, dtype=torch.int32)
+    out = sort_sharded_u32(NumpyEngine(), keys, recv, dist, world)
+    q.put((rank, out.numpy().view(np.uint32).copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "uniform"), (4, "uniform"), (2, "zipf")])
+def test_sharded_sort_over_gloo(world, kind):
+    n = 20000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    gen = O.gen_uniform_u32 if kind == "uniform" else O.gen_zipf_u32
+    allk = np.concatenate([gen(n, first=r * n) for r in range(world)])
+    got = np.concatenate([res[r] for r in range(world)])
+    assert (got == O.sort_u32(allk)).all()
+    for r in range(world):  # rank r owns top bits == r
+        if res[r].size:
+            lg = world.bit_length() - 1
+            assert ((res[r] >> np.uint32(32 - lg)) == r).all()
+
+
+def test_splitters_follow_the_reference_duplicate_rule():
+    from inplacemsdradixsort_amd.dist import splitters_equi_depth
+    from oracle import oracle as O
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    import ctypes as C
+    s = np.sort(O.gen_zipf_u32(4000, seed=3).astype(np.uint64))
+    parts = 8
+    delim = np.zeros(parts, np.uint64)
+    delim[parts - 1] = np.uint64(2**64 - 1)  # terminator the reference scans for (src/msb_64.c:1307)
+    L = O.ref().lib
+    L.extract_delimiters.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
+    L.extract_delimiters(s.ctypes.data_as(C.POINTER(C.c_uint64)), s.size, delim.ctypes.data_as(C.POINTER(C.c_uint64)))
+    assert splitters_equi_depth(s, parts) == delim[:parts - 1].tolist()
