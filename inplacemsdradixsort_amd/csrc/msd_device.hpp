@@ -31,8 +31,10 @@ namespace msd {
 constexpr int kP = 256;              // buckets per digit pass (8-bit digits)
 constexpr uint32_t kXBase = 0x80000000u; // slot ids >= kXBase live in the side block store
 constexpr uint32_t kNoOwner = 0xFFFFFFFFu;
+constexpr uint32_t kRposStride = 32;    // claim cursors sit on separate 128-byte lines
 
 struct NoVal {};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // one 16-byte register quad
 
 template <typename V> struct has_val { static constexpr bool value = true; };
 template <> struct has_val<NoVal> { static constexpr bool value = false; };
@@ -41,7 +43,7 @@ template <> struct has_val<NoVal> { static constexpr bool value = false; };
 // blocks), T = elements per classify tile, TH = classify threads.
 template <typename K, typename V> struct Cfg;
 template <> struct Cfg<uint32_t, NoVal> {
-	static constexpr int B = 64, T = 4096, TH = 512;
+	static constexpr int B = 64, T = 2048, TH = 512;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 24; // LDS sort capacity 24576
 };
 template <> struct Cfg<uint64_t, NoVal> {
@@ -428,6 +430,7 @@ __global__ __launch_bounds__(256) void child_scan_kernel(const Parent *__restric
 	const Parent pa = parents[blockIdx.x];
 	const uint32_t d = threadIdx.x;
 	uint64_t F = 0, ls = 0;
+#pragma unroll 8
 	for (uint32_t s = pa.stripe_lo; s < pa.stripe_hi; ++s) {
 		const size_t o = (size_t)s * kP + d;
 		F += fb[o];
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(256) void child_scan_kernel(const Parent *__restric
 		ca.n_fr[ci] = 0;
 		ca.cur_int[ci] = 0;
 		ca.cur_fr[ci] = 0;
-		ca.rpos[ci] = 0;
+		ca.rpos[(size_t)ci * kRposStride] = 0;
 	}
 }
 
@@ -472,16 +475,18 @@ __device__ __forceinline__ int slot_owner(const uint32_t *is, const uint32_t *ie
 
 // Pass 1 (SCATTER = false): count misplaced blocks per (child, class) and record holes.
 // Pass 2 (SCATTER = true): write the per-child lists, interior-class entries first.
+// Global atomics are issued once per (workgroup, child, class) / once per wave (holes);
+// positions inside a reservation come from LDS fetch-adds.
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, const uint8_t *__restrict__ block_map,
 	const uint32_t *__restrict__ nfull, ChildArrays ca, ListEntry *__restrict__ list,
 	ListEntry *__restrict__ holes, Counters *__restrict__ ctr)
 {
-	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP];
+	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP], s_base[2][kP];
 	const Stripe st = stripes[blockIdx.x];
 	const Parent pa = parents[st.parent];
-	const uint32_t W = 1u << pa.width, tid = threadIdx.x;
+	const uint32_t W = 1u << pa.width, tid = threadIdx.x, lane = tid & 63;
 	if (tid < W) {
 		s_is[tid] = ca.is[pa.child_base + tid];
 		s_ie[tid] = s_is[tid] + ca.I[pa.child_base + tid];
@@ -490,43 +495,65 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	s_cls[1][tid] = 0;
 	__syncthreads();
 	const uint32_t nf = nfull[blockIdx.x];
-	for (uint32_t i = st.slot_lo + tid; i < st.slot_hi; i += 256) {
-		const int own = slot_owner(s_is, s_ie, W, i);
-		if (i - st.slot_lo < nf) {
-			const uint32_t d = block_map[i];
-			if ((int)d != own) {
-				const uint32_t cls = own >= 0 ? 0 : 1;
-				if (!SCATTER)
-					atomicAdd(&s_cls[cls][d], 1u);
-				else {
-					const uint32_t ci = pa.child_base + d;
-					uint32_t p;
-					uint64_t base = ca.list_base[ci];
-					if (cls == 0)
-						p = atomicAdd(&ca.cur_int[ci], 1u);
-					else {
-						p = atomicAdd(&ca.cur_fr[ci], 1u);
-						base += ca.n_int0[ci];
-					}
+	const uint32_t nsl = st.slot_hi - st.slot_lo;
+	// ---- count (both passes need the per-workgroup counts)
+	for (uint32_t o = tid; o < ((nsl + 255) & ~255u); o += 256) {
+		const uint32_t i = st.slot_lo + o;
+		bool hole = false;
+		int own = -1;
+		if (o < nsl) {
+			own = slot_owner(s_is, s_ie, W, i);
+			if (o < nf) {
+				const uint32_t d = block_map[i];
+				if ((int)d != own) atomicAdd(&s_cls[own >= 0 ? 0 : 1][d], 1u);
+			} else
+				hole = own >= 0;
+		}
+		if (!SCATTER) { // holes: one global fetch-add per wave
+			const uint64_t hm = __ballot(hole);
+			if (hm) {
+				const int ldr = __ffsll((long long)hm) - 1;
+				uint32_t base = 0;
+				if ((int)lane == ldr) base = atomicAdd(&ctr->nholes, (uint32_t)__popcll(hm));
+				base = __shfl(base, ldr);
+				if (hole) {
 					ListEntry e;
 					e.slot = i;
-					e.owner = own >= 0 ? pa.child_base + (uint32_t)own : kNoOwner;
-					list[base + p] = e;
+					e.owner = pa.child_base + (uint32_t)own;
+					holes[base + __popcll(hm & ((1ull << lane) - 1ull))] = e;
 				}
 			}
-		} else if (!SCATTER && own >= 0) {
-			const uint32_t p = atomicAdd(&ctr->nholes, 1u);
-			ListEntry e;
-			e.slot = i;
-			e.owner = pa.child_base + (uint32_t)own;
-			holes[p] = e;
 		}
 	}
+	__syncthreads();
 	if (!SCATTER) {
-		__syncthreads();
 		if (tid < W) {
 			if (s_cls[0][tid]) atomicAdd(&ca.n_int[pa.child_base + tid], s_cls[0][tid]);
 			if (s_cls[1][tid]) atomicAdd(&ca.n_fr[pa.child_base + tid], s_cls[1][tid]);
+		}
+		return;
+	}
+	// ---- reserve list ranges for this workgroup, then place entries
+	if (tid < W) {
+		const uint32_t ci = pa.child_base + tid;
+		const uint32_t lb = (uint32_t)ca.list_base[ci];
+		s_base[0][tid] = lb + (s_cls[0][tid] ? atomicAdd(&ca.cur_int[ci], s_cls[0][tid]) : 0);
+		s_base[1][tid] = lb + ca.n_int0[ci] + (s_cls[1][tid] ? atomicAdd(&ca.cur_fr[ci], s_cls[1][tid]) : 0);
+		s_cls[0][tid] = 0;
+		s_cls[1][tid] = 0;
+	}
+	__syncthreads();
+	for (uint32_t o = tid; o < nf && o < nsl; o += 256) {
+		const uint32_t i = st.slot_lo + o;
+		const int own = slot_owner(s_is, s_ie, W, i);
+		const uint32_t d = block_map[i];
+		if ((int)d != own) {
+			const uint32_t cls = own >= 0 ? 0 : 1;
+			const uint32_t p = s_base[cls][d] + atomicAdd(&s_cls[cls][d], 1u);
+			ListEntry e;
+			e.slot = i;
+			e.owner = own >= 0 ? pa.child_base + (uint32_t)own : kNoOwner;
+			list[p] = e;
 		}
 	}
 }
@@ -600,6 +627,8 @@ __global__ __launch_bounds__(64) void evict_kernel(uint32_t nchildren, ChildArra
 // hole's bucket (fetch-add on the bucket's list cursor) -> the wave moves the 64
 // claimed blocks -> the vacated slot is the lane's next hole, unless the claimed
 // entry was fringe-class, which ends the chain.  No lane ever waits for another.
+// Lanes of a wave that claim from the same bucket share one fetch-add (skewed inputs
+// put most chains into one bucket).
 template <typename K, typename V>
 __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListEntry *__restrict__ list,
 	const ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
@@ -611,7 +640,9 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 	constexpr int LPB = B / VEC;      // lanes per block (16)
 	constexpr int BPI = 64 / LPB;     // blocks per wave instruction (4)
 	constexpr int NI = 64 / BPI;      // instructions to move 64 blocks (16)
+	constexpr int GROUPS = 4;         // shared claims are formed for the 4 most common buckets
 	const uint32_t lane = lane_id();
+	const uint64_t lt = (1ull << lane) - 1ull;
 	const uint32_t nholes = ctr->nholes;
 	uint32_t hole = 0, owner = 0;
 	bool active = false, exhausted = false;
@@ -623,11 +654,12 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 			const uint64_t need = __ballot(!active);
 			if (need) {
 				const uint32_t n = __popcll(need);
+				const int ldr = __ffsll((long long)need) - 1;
 				uint32_t base = 0;
-				if (lane == (uint32_t)(__ffsll((long long)need) - 1)) base = atomicAdd(&ctr->hole_cursor, n);
-				base = __shfl(base, __ffsll((long long)need) - 1);
+				if ((int)lane == ldr) base = atomicAdd(&ctr->hole_cursor, n);
+				base = __shfl(base, ldr);
 				if (!active) {
-					const uint32_t my = base + __popcll(need & ((1ull << lane) - 1ull));
+					const uint32_t my = base + __popcll(need & lt);
 					if (my < nholes) {
 						const ListEntry e = holes[my];
 						hole = e.slot;
@@ -641,17 +673,37 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 		const uint64_t act = __ballot(active);
 		if (!act) break;
 
-		// ---- claim one source block per active lane
+		// ---- claim one source block per active lane; lanes with equal owner share a fetch-add
+		uint64_t rem = act;
+		int my_ldr = (int)lane;
+		uint32_t my_rank = 0, my_cnt = 1;
+#pragma unroll
+		for (int g = 0; g < GROUPS; ++g) {
+			if (rem) {
+				const int l = __ffsll((long long)rem) - 1;
+				const uint32_t o = __shfl(owner, l);
+				const uint64_t same = __ballot(active && owner == o) & rem;
+				if ((same >> lane) & 1ull) {
+					my_ldr = l;
+					my_rank = __popcll(same & lt);
+					my_cnt = __popcll(same);
+				}
+				rem &= ~same;
+			}
+		}
+		uint32_t idx = 0;
+		if (active && my_ldr == (int)lane) idx = atomicAdd(&ca.rpos[(size_t)owner * kRposStride], my_cnt);
+		idx = __shfl(idx, my_ldr) + my_rank;
+
 		uint32_t src = 0, src_owner = kNoOwner;
 		bool last = false;
 		if (active) {
-			const uint32_t idx = atomicAdd(&ca.rpos[owner], 1u);
 			const uint32_t len = (uint32_t)ca.list_len[owner];
 			if (idx >= len) { // cannot happen when the bookkeeping is right
 				atomicAdd(&ctr->errors, 1u);
 				active = false;
 			} else {
-				const ListEntry e = list[ca.list_base[owner] + idx];
+				const ListEntry e = list[(uint32_t)ca.list_base[owner] + idx];
 				src = e.slot;
 				src_owner = e.owner;
 				last = idx >= ca.n_int[owner];
@@ -660,28 +712,28 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 		const uint64_t mv = __ballot(active);
 		++steps;
 
-		// ---- move the claimed blocks: lane group g of instruction i serves chain i*BPI+g
-		uint4 kd[NI];
-		uint4 vd[HV ? NI : 1];
+		// ---- move the claimed blocks: lane group g of instruction i serves chain i*BPI+g.
+		// Loads are unconditional (idle chains read slot 0) so that the 16 vectors stay in registers.
 		const uint32_t sub = lane % LPB;
+		const uint32_t src_safe = active ? src : 0u;
+		u32x4 kd[NI];
+		u32x4 vd[HV ? NI : 1];
 #pragma unroll
 		for (int i = 0; i < NI; ++i) {
 			const int chain = i * BPI + (int)(lane / LPB);
-			const uint32_t s = __shfl(src, chain);
-			if ((mv >> chain) & 1ull) {
-				kd[i] = *reinterpret_cast<const uint4 *>(slot_ptr<K, B>(keys, xkeys, s) + sub * VEC);
-				if constexpr (HV)
-					vd[i] = *reinterpret_cast<const uint4 *>(slot_ptr<uint64_t, B>(vals, xvals, s) + sub * VEC);
-			}
+			const uint32_t s = __shfl(src_safe, chain);
+			kd[i] = *reinterpret_cast<const u32x4 *>(slot_ptr<K, B>(keys, xkeys, s) + sub * VEC);
+			if constexpr (HV)
+				vd[i] = *reinterpret_cast<const u32x4 *>(slot_ptr<uint64_t, B>(vals, xvals, s) + sub * VEC);
 		}
 #pragma unroll
 		for (int i = 0; i < NI; ++i) {
 			const int chain = i * BPI + (int)(lane / LPB);
 			const uint32_t hdst = __shfl(hole, chain);
 			if ((mv >> chain) & 1ull) {
-				*reinterpret_cast<uint4 *>(slot_ptr<K, B>(keys, xkeys, hdst) + sub * VEC) = kd[i];
+				*reinterpret_cast<u32x4 *>(slot_ptr<K, B>(keys, xkeys, hdst) + sub * VEC) = kd[i];
 				if constexpr (HV)
-					*reinterpret_cast<uint4 *>(slot_ptr<uint64_t, B>(vals, xvals, hdst) + sub * VEC) = vd[i];
+					*reinterpret_cast<u32x4 *>(slot_ptr<uint64_t, B>(vals, xvals, hdst) + sub * VEC) = vd[i];
 			}
 		}
 		if (active) {
@@ -701,7 +753,7 @@ __global__ __launch_bounds__(256) void chains_verify_kernel(uint32_t nchildren, 
 {
 	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
 	if (ci >= nchildren) return;
-	if (ca.rpos[ci] != (uint32_t)ca.list_len[ci]) atomicAdd(&ctr->errors, 1u);
+	if (ca.rpos[(size_t)ci * kRposStride] != (uint32_t)ca.list_len[ci]) atomicAdd(&ctr->errors, 1u);
 }
 
 // ------------------------------------------------------------- C: cleanup
@@ -807,7 +859,8 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 // One workgroup sorts one segment of <= SORT_TH*SORT_KPT elements on its low
 // `bits` bits: stable LSD passes of 8 bits inside LDS.  Keys live in registers in
 // wave-striped order; the per-wave rank of a key among equal digits comes from a
-// match-any built with 8 wavefront ballots and a popcount of the lower lanes.
+// match-any built with 8 wavefront ballots and a popcount of the lower lanes, plus
+// a per-wave running digit counter in LDS (read by all peers, bumped by the lowest).
 template <typename K, typename V>
 __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__restrict__ keys,
 	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs)
@@ -827,7 +880,8 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 	const Segment sg = segs[blockIdx.x];
 	const uint32_t n = (uint32_t)sg.count;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const uint32_t wbase = w * (KPT * 64);
+	const int nitems = (int)((n + TH - 1) / TH);         // items per thread actually in use
+	const uint32_t wbase = w * (uint32_t)nitems * 64;    // wave-striped layout over [0, nitems*TH)
 	const uint64_t lt_mask = (1ull << lane) - 1ull;
 
 	K kr[KPT];
@@ -835,15 +889,16 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 	K k_or = 0, k_and = ~(K)0;
 #pragma unroll
 	for (int i = 0; i < KPT; ++i) {
-		const uint32_t idx = wbase + i * 64 + lane;
-		if (idx < n) {
-			kr[i] = keys[sg.start + idx];
-			if constexpr (HV) vr[i] = vals[sg.start + idx];
-			k_or |= kr[i];
-			k_and &= kr[i];
-		} else {
-			kr[i] = ~(K)0;
-			if constexpr (HV) vr[i] = 0;
+		kr[i] = ~(K)0;
+		if constexpr (HV) vr[i] = 0;
+		if (i < nitems) {
+			const uint32_t idx = wbase + i * 64 + lane;
+			if (idx < n) {
+				kr[i] = keys[sg.start + idx];
+				if constexpr (HV) vr[i] = vals[sg.start + idx];
+				k_or |= kr[i];
+				k_and &= kr[i];
+			}
 		}
 	}
 	// which bits vary inside the segment (passes over constant digits are skipped)
@@ -867,6 +922,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 	const K vary = s_or[0] ^ s_or[1];
 	__syncthreads();
 
+	uint32_t *mycnt = wcnt + w * kP;
 	bool in_lds = false;
 	for (uint32_t shift = 0; shift < sg.bits; shift += 8) {
 		const uint32_t width = sg.bits - shift < 8 ? sg.bits - shift : 8;
@@ -874,27 +930,25 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 		if (((uint32_t)(vary >> shift) & mask) == 0) continue; // digit constant over the segment
 		for (uint32_t j = tid; j < NW * kP; j += TH) wcnt[j] = 0;
 		__syncthreads();
-		uint32_t rk[KPT];
-		uint32_t *mycnt = wcnt + w * kP;
+		uint32_t rk[(KPT + 1) / 2]; // two 16-bit ranks per register
 #pragma unroll
 		for (int i = 0; i < KPT; ++i) {
-			const uint32_t d = digit_of(kr[i], shift, mask);
-			uint64_t peers = ~0ull;
+			if (i < nitems) {
+				const uint32_t d = digit_of(kr[i], shift, mask);
+				uint64_t peers = ~0ull;
 #pragma unroll
-			for (int b = 0; b < 8; ++b) {
-				const bool bit = (d >> b) & 1u;
-				const uint64_t m = __ballot(bit);
-				peers &= bit ? m : ~m;
+				for (int b = 0; b < 8; ++b) {
+					const bool bit = (d >> b) & 1u;
+					const uint64_t m = __ballot(bit);
+					peers &= bit ? m : ~m;
+				}
+				const uint32_t below = __popcll(peers & lt_mask);
+				const uint32_t old = mycnt[d];                          // same value for all peers
+				if (below == 0) mycnt[d] = old + __popcll(peers);       // lowest peer bumps the counter
+				const uint32_t r = old + below;                         // < nitems*64 <= 1536
+				if (i & 1) rk[i / 2] |= r << 16; else rk[i / 2] = r;
 			}
-			const uint32_t below = __popcll(peers & lt_mask);
-			const int leader = __ffsll((long long)peers) - 1;
-			uint32_t old = 0;
-			if ((int)lane == leader) {
-				old = mycnt[d];
-				mycnt[d] = old + __popcll(peers);
-			}
-			old = __shfl(old, leader);
-			rk[i] = (old + below) | (d << 24); // rank < 2^24
+			__builtin_amdgcn_sched_barrier(0); // keep one item's ballots live at a time
 		}
 		__syncthreads();
 		// exclusive offsets: digit-major, wave-minor
@@ -913,10 +967,13 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 		__syncthreads();
 #pragma unroll
 		for (int i = 0; i < KPT; ++i) {
-			const uint32_t d = rk[i] >> 24;
-			const uint32_t p = dbase[d] + mycnt[d] + (rk[i] & 0xFFFFFFu);
-			xk[p] = kr[i];
-			if constexpr (HV) xv[p] = vr[i];
+			if (i < nitems) {
+				const uint32_t d = digit_of(kr[i], shift, mask);
+				const uint32_t r = (i & 1) ? rk[i / 2] >> 16 : rk[i / 2] & 0xFFFFu;
+				const uint32_t p = dbase[d] + mycnt[d] + r;
+				xk[p] = kr[i];
+				if constexpr (HV) xv[p] = vr[i];
+			}
 		}
 		__syncthreads();
 		in_lds = true;
@@ -929,8 +986,10 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 		if (!more) break;
 #pragma unroll
 		for (int i = 0; i < KPT; ++i) {
-			kr[i] = xk[wbase + i * 64 + lane];
-			if constexpr (HV) vr[i] = xv[wbase + i * 64 + lane];
+			if (i < nitems) {
+				kr[i] = xk[wbase + i * 64 + lane];
+				if constexpr (HV) vr[i] = xv[wbase + i * 64 + lane];
+			}
 		}
 		__syncthreads();
 		in_lds = false;

@@ -298,7 +298,7 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 	rb.ca.cur_fr = b.take<uint32_t>(nc);
 	rb.ca.list_len = b.take<uint64_t>(nc);
 	rb.ca.list_base = b.take<uint64_t>(nc);
-	rb.ca.rpos = b.take<uint32_t>(nc);
+	rb.ca.rpos = b.take<uint32_t>((size_t)nc * kRposStride);
 	rb.ca.flags = b.take<uint32_t>(nc);
 	rb.list = b.take<ListEntry>(rp.nslots + 1);
 	// holes: tail slots (< kP + 2 per stripe) + one eviction + one excess per child
