@@ -35,6 +35,7 @@ KERNEL_ALGO = {
     "A classify": ("classify_kernel<u32>", 6.0),       # per key per round
     "B block permute": ("chains_kernel<u32>", 6.0),    # per key per round
     "LDS sort": ("lds_sort_kernel<u32>", None),        # remaining passes x 12 B per key
+    "count sort": ("count_sort_kernel<u32>", None),    # remaining passes x 12 B per key
 }
 
 

@@ -90,7 +90,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t nsmall;       // cumulative
 	uint32_t errors;       // cumulative: internal invariant violations
 	uint32_t chain_steps;  // cumulative (stat)
-	uint32_t pad[2];
+	uint32_t ncount;       // cumulative: segments for the one-pass counting sort (<= 16 bits left)
+	uint32_t nfallback;    // counting-sort segments handed to the general LDS sort (byte counter overflow)
 };
 
 // ---------------------------------------------------------------- utilities
@@ -826,9 +827,10 @@ __global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArr
 	}
 }
 
-// children -> next round's parents / the small-segment list / done
+// children -> next round's parents / the small-segment lists / done
 __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, ChildArrays ca,
-	uint64_t small_max, uint32_t small_cap, Segment *__restrict__ next_parents, Segment *__restrict__ small,
+	uint64_t small_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
+	Segment *__restrict__ small, Segment *__restrict__ small_count,
 	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out)
 {
 	const Parent pa = parents[blockIdx.x];
@@ -845,12 +847,120 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 	s.pad = 0;
 	if (c > small_max)
 		next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
-	else {
+	else if (pa.shift <= count_bits && c >= 64) { // all remaining bits in one unstable counting pass
+		const uint32_t at = atomicAdd(&ctr->ncount, 1u);
+		if (at < small_cap) small_count[at] = s; else atomicAdd(&ctr->errors, 1u);
+	} else {
 		const uint32_t at = atomicAdd(&ctr->nsmall, 1u);
-		if (at < small_cap)
-			small[at] = s;
-		else
-			atomicAdd(&ctr->errors, 1u);
+		if (at < small_cap) small[at] = s; else atomicAdd(&ctr->errors, 1u);
+	}
+}
+
+// ------------------------------------------------- one-pass counting sort
+
+// A segment whose keys differ only in their low `bits` <= 16 bits is finished in ONE
+// pass over all of those bits, so the pass needs no stability: 2^bits byte counters in
+// LDS are bumped with LDS fetch-adds and, the keys being nothing but (common prefix |
+// counted value), the sorted segment is re-generated from the counters -- no key is
+// moved at all.  A value that occurs more than 255 times overflows its byte: the
+// workgroup then leaves the segment untouched and queues it for the general LDS sort.
+constexpr int kCountTh = 1024;
+constexpr int kCountMaxBits = 16;
+// counter word i lives at i + i/32: a thread's 16 consecutive words and its neighbours' then
+// fall on different LDS banks (unpadded, the stride-16 walk is a 32-way bank conflict)
+constexpr size_t kCountCwBytes = (((size_t)1 << kCountMaxBits) / 4 + ((size_t)1 << kCountMaxBits) / 128 + 4) * 4;
+constexpr int kCountStageBytes = 14080; // output window; with the counters: two workgroups per CU
+constexpr size_t kCountLds = kCountCwBytes + kCountStageBytes + 128;
+__device__ __forceinline__ uint32_t cw_at(uint32_t i) { return i + (i >> 5); }
+
+template <typename K>
+__global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ keys,
+	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ fallback, uint32_t fallback_base,
+	Counters *__restrict__ ctr)
+{
+	constexpr uint32_t WS = kCountStageBytes / sizeof(K); // keys per output window
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);    // packed byte counters (padded layout)
+	K *stage = reinterpret_cast<K *>(smem + kCountCwBytes);
+	uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + kCountCwBytes + kCountStageBytes); // 16 wave totals
+	uint32_t *flag = wtot + 16;
+	if (blockIdx.x >= nsegs) return;
+	const Segment sg = segs[blockIdx.x];
+	const uint32_t n = (uint32_t)sg.count, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t nv = 1u << sg.bits, mask = nv - 1u;
+	const uint32_t nwords = nv >= 4 ? nv / 4 : 1;
+	K *seg = keys + sg.start;
+
+	for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
+	if (tid == 0) *flag = 0;
+	__syncthreads();
+	const K hi = seg[0] & ~(K)mask; // common prefix of the whole segment
+	bool ovf = false;
+	for (uint32_t i0 = 0; i0 < n; i0 += 4 * kCountTh) {
+		K k4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t idx = i0 + u * kCountTh + tid;
+			k4[u] = idx < n ? seg[idx] : (K)0;
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t idx = i0 + u * kCountTh + tid;
+			if (idx < n) {
+				const uint32_t v = (uint32_t)k4[u] & mask, sh = (v & 3u) * 8u;
+				const uint32_t old = atomicAdd(&cw[cw_at(v >> 2)], 1u << sh);
+				ovf |= ((old >> sh) & 0xFFu) == 0xFFu;
+			}
+		}
+	}
+	if (ovf) *flag = 1;
+	__syncthreads();
+	if (*flag) { // some value occurs > 255 times: hand the untouched segment to the general sort
+		if (tid == 0) {
+			const uint32_t at = atomicAdd(&ctr->nfallback, 1u);
+			fallback[fallback_base + at] = sg;
+		}
+		return;
+	}
+	// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
+	const uint32_t wpt = nwords >= kCountTh ? nwords / kCountTh : 1;
+	const uint32_t w0 = tid * wpt;
+	uint32_t tot = 0;
+	uint64_t nz = 0; // one bit per non-empty byte counter of this thread
+	if (w0 < nwords) {
+		for (uint32_t j = 0; j < wpt; ++j) {
+			const uint32_t x = cw[cw_at(w0 + j)];
+			tot = __builtin_amdgcn_sad_u8(x, 0u, tot); // byte sum
+			const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
+			nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
+		}
+	}
+	const uint32_t inc = wave_incl_scan(tot);
+	if (lane == 63) wtot[w] = inc;
+	__syncthreads();
+	uint32_t pos = inc - tot;
+	for (uint32_t ww = 0; ww < w; ++ww) pos += wtot[ww];
+	const uint32_t end = pos + tot;
+	// ---- re-generate the sorted keys window by window through LDS (coalesced stores).
+	// A thread's keys form one ascending run [pos, end); it resumes where the last window cut it.
+	uint32_t c = 0;
+	K cur = 0;
+	for (uint32_t wbeg = 0; wbeg < n; wbeg += WS) {
+		const uint32_t wend = wbeg + WS < n ? wbeg + WS : n;
+		while (pos < end && pos < wend) {
+			if (c == 0) { // next non-empty counter (one exists because pos < end)
+				const uint32_t i = (uint32_t)__ffsll((long long)nz) - 1u;
+				nz &= nz - 1;
+				c = (cw[cw_at(w0 + (i >> 2))] >> (8u * (i & 3u))) & 0xFFu;
+				cur = hi | (K)((w0 + (i >> 2)) * 4u + (i & 3u));
+			}
+			stage[pos - wbeg] = cur;
+			++pos;
+			--c;
+		}
+		__syncthreads();
+		for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = stage[i];
+		__syncthreads();
 	}
 }
 
@@ -863,11 +973,13 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 // a per-wave running digit counter in LDS (read by all peers, bumped by the lowest).
 template <typename K, typename V>
 __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__restrict__ keys,
-	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs)
+	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs,
+	const uint32_t *__restrict__ nsegs_dev)
 {
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
 	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, NW = TH / 64, CAP = TH * KPT;
+	if (nsegs_dev) nsegs = *nsegs_dev; // list filled by an earlier kernel of this stream
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	K *xk = reinterpret_cast<K *>(smem);
 	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
@@ -935,16 +1047,18 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 		for (int i = 0; i < KPT; ++i) {
 			if (i < nitems) {
 				const uint32_t d = digit_of(kr[i], shift, mask);
-				uint64_t peers = ~0ull;
+				uint32_t plo = ~0u, phi = ~0u; // match-any: lanes of this wave with the same digit
 #pragma unroll
 				for (int b = 0; b < 8; ++b) {
-					const bool bit = (d >> b) & 1u;
-					const uint64_t m = __ballot(bit);
-					peers &= bit ? m : ~m;
+					const uint32_t bit = (d >> b) & 1u;
+					const uint64_t m = __ballot(bit != 0);
+					const uint32_t ext = bit - 1u; // 0 when the bit is set, ~0 otherwise
+					plo &= (uint32_t)m ^ ext;
+					phi &= (uint32_t)(m >> 32) ^ ext;
 				}
-				const uint32_t below = __popcll(peers & lt_mask);
+				const uint32_t below = __popc(plo & (uint32_t)lt_mask) + __popc(phi & (uint32_t)(lt_mask >> 32));
 				const uint32_t old = mycnt[d];                          // same value for all peers
-				if (below == 0) mycnt[d] = old + __popcll(peers);       // lowest peer bumps the counter
+				if (below == 0) mycnt[d] = old + __popc(plo) + __popc(phi); // lowest peer bumps the counter
 				const uint32_t r = old + below;                         // < nitems*64 <= 1536
 				if (i & 1) rk[i / 2] |= r << 16; else rk[i / 2] = r;
 			}

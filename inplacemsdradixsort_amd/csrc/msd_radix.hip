@@ -342,7 +342,8 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 	Bump b(nullptr);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
 	b.take<Counters>(1);
-	b.take<Segment>(small_list_cap<K, V>(n));
+	b.take<Segment>(small_list_cap<K, V>(n) * 2); // general list (+ counting-sort fallbacks behind it)
+	b.take<Segment>(small_list_cap<K, V>(n));     // counting-sort list
 	return b.off + 4096;
 }
 
@@ -409,10 +410,13 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	Bump kb(c->keep);
 	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
 	Counters *ctr = kb.take<Counters>(1);
-	Segment *small = kb.take<Segment>(small_cap);
+	Segment *small = kb.take<Segment>(small_cap * 2);
+	Segment *small_count = kb.take<Segment>(small_cap);
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
+	// keys without payload whose last <= 16 bits are open are finished by the counting sort
+	const uint32_t count_bits = HV ? 0u : (uint32_t)kCountMaxBits;
 
-	uint32_t nsmall_host = 0;
+	uint32_t nsmall_host = 0, ncount_host = 0;
 	if (!single_pass && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(c->pinned, &cur[0], sizeof(Segment));
@@ -495,7 +499,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				   rb.lo_off, rb.lo_dst, rb.ca, (const K *)rb.lo_keys, rb.lo_vals, keys, vals);
 		hipLaunchKernelGGL((excess_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, (const K *)rb.xkeys, rb.xvals, keys, vals);
 		hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, rb.parents, rb.ca,
-				   single_pass ? ~0ull : small_max, (uint32_t)small_cap, rb.next_parents, small, ctr,
+				   single_pass ? ~0ull : small_max, (uint32_t)small_cap, single_pass ? 0u : count_bits,
+				   rb.next_parents, small, small_count, ctr,
 				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "C cleanup");
@@ -507,6 +512,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		memcpy(&hc, c->pinned, sizeof hc);
 		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations", round, hc.errors);
 		nsmall_host = hc.nsmall;
+		ncount_host = hc.ncount;
 		add_stat(c, "rounds", 1);
 		add_stat(c, "parents", np);
 		add_stat(c, "stripes", ns);
@@ -530,13 +536,29 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 
 	// ---- segments that fit LDS are finished there
-	if (nsmall_host && !single_pass) {
+	if (!single_pass) {
 		constexpr size_t sort_lds = SortLds<K, V>::bytes;
-		hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), sort_lds, c->stream,
-				   keys, vals, small, nsmall_host);
-		HIPCHK(c, hipGetLastError());
+		if constexpr (!HV) {
+			if (ncount_host) { // one unstable counting pass over all remaining bits
+				hipLaunchKernelGGL((count_sort_kernel<K>), dim3(ncount_host), dim3(kCountTh), kCountLds, c->stream,
+						   keys, small_count, ncount_host, small, nsmall_host, ctr);
+				HIPCHK(c, hipGetLastError());
+				phase_mark(c, "count sort");
+			}
+		}
+		if (nsmall_host) {
+			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), sort_lds, c->stream,
+					   keys, vals, small, nsmall_host, (const uint32_t *)nullptr);
+			HIPCHK(c, hipGetLastError());
+		}
+		if (ncount_host) { // counting-sort overflows (count only known on the device)
+			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(ncount_host), dim3(C::SORT_TH), sort_lds, c->stream,
+					   keys, vals, small + nsmall_host, 0u, (const uint32_t *)&ctr->nfallback);
+			HIPCHK(c, hipGetLastError());
+		}
 		phase_mark(c, "LDS sort");
 	}
+	set_stat(c, "count_segments", ncount_host);
 	set_stat(c, "small_segments", nsmall_host);
 	set_stat(c, "workspace_bytes", c->slab_bytes + c->keep_bytes);
 	phase_end(c);
@@ -549,6 +571,9 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
+	if constexpr (!has_val<V>::value)
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_sort_kernel<K>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
 	return MSD_OK;
 }
 
