@@ -980,6 +980,8 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 	constexpr bool HV = has_val<V>::value;
 	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, NW = TH / 64, CAP = TH * KPT;
 	if (nsegs_dev) nsegs = *nsegs_dev; // list filled by an earlier kernel of this stream
+	for (uint32_t sgi = blockIdx.x; sgi < nsegs; sgi += gridDim.x) { // (grid may be smaller than the list)
+	__syncthreads();
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	K *xk = reinterpret_cast<K *>(smem);
 	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
@@ -988,8 +990,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 	uint32_t *tmp = dbase + kP;       // 8
 	K *s_or = reinterpret_cast<K *>(tmp + 8); // [2]: OR and AND of the keys (varying-bit detection)
 
-	if (blockIdx.x >= nsegs) return;
-	const Segment sg = segs[blockIdx.x];
+	const Segment sg = segs[sgi];
 	const uint32_t n = (uint32_t)sg.count;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	const int nitems = (int)((n + TH - 1) / TH);         // items per thread actually in use
@@ -1115,6 +1116,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 		}
 	}
 	// (no varying digit at all: the segment is constant on the bits in question, nothing to do)
+	} // segment loop
 }
 
 template <typename K, typename V> struct SortLds {

@@ -29,6 +29,8 @@ struct msd_ctx {
 	size_t slab_bytes = 0;
 	char *keep = nullptr; // device workspace that lives for the whole call
 	size_t keep_bytes = 0;
+	Segment *lists = nullptr; // leaf-segment lists: [general: 2*cap][counting sort: cap]
+	size_t lists_cap = 0;
 	void *pinned = nullptr; // small host staging (pinned)
 	size_t pinned_bytes = 0;
 	std::string err;
@@ -101,6 +103,26 @@ static int dev_reserve(msd_ctx *c, char *&p, size_t &have, size_t bytes)
 }
 static int slab_reserve(msd_ctx *c, size_t bytes) { return dev_reserve(c, c->slab, c->slab_bytes, bytes); }
 static int keep_reserve(msd_ctx *c, size_t bytes) { return dev_reserve(c, c->keep, c->keep_bytes, bytes); }
+
+// Leaf lists grow between rounds (the host knows how many children a round can add);
+// live entries are carried over.
+static int lists_reserve(msd_ctx *c, size_t need, size_t live_general, size_t live_count)
+{
+	if (need <= c->lists_cap) return MSD_OK;
+	const size_t cap = align_up(need + need / 2, 4096);
+	Segment *nb = nullptr;
+	hipError_t e = hipMalloc((void **)&nb, 3 * cap * sizeof(Segment));
+	if (e != hipSuccess) return fail(c, MSD_ENOMEM, "leaf list hipMalloc failed: %s", hipGetErrorString(e));
+	if (c->lists) {
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		if (live_general) HIPCHK(c, hipMemcpy(nb, c->lists, live_general * sizeof(Segment), hipMemcpyDeviceToDevice));
+		if (live_count) HIPCHK(c, hipMemcpy(nb + 2 * cap, c->lists + 2 * c->lists_cap, live_count * sizeof(Segment), hipMemcpyDeviceToDevice));
+		HIPCHK(c, hipFree(c->lists));
+	}
+	c->lists = nb;
+	c->lists_cap = cap;
+	return MSD_OK;
+}
 
 struct Bump { // sizing pass (base == nullptr) or carving pass
 	char *base;
@@ -194,18 +216,25 @@ static uint32_t ceil_log2_u64(uint64_t x)
 	return p;
 }
 
-// Digit width for a parent: 8 bits for big parents, fewer when that already
-// brings the children down to about half the LDS-sort capacity.
-static uint32_t pick_width(uint64_t count, uint32_t bits, uint64_t small_max)
+// Digit width for a parent: 8 bits for big parents, fewer when that already brings
+// the children down to about half the LDS-sort capacity.  `leaf_bits` > 0 (keys without
+// payload): children that are leaves should keep <= leaf_bits open bits so that the
+// one-pass counting sort can finish them.
+static uint32_t pick_width(uint64_t count, uint32_t bits, uint64_t small_max, uint32_t leaf_bits)
 {
 	uint64_t target = small_max / 2;
 	uint32_t w = ceil_log2_u64((count + target - 1) / target);
 	w = std::max(1u, std::min(8u, w));
-	return std::min(w, bits);
+	w = std::min(w, bits);
+	// widen only while the leaves stay big enough to amortise the counting sort's 64 KiB of counters
+	if (leaf_bits && bits - w > leaf_bits && bits <= leaf_bits + 8 && (count >> (bits - leaf_bits)) <= small_max &&
+	    (count >> (bits - leaf_bits)) >= 2048)
+		w = bits - leaf_bits;
+	return w;
 }
 
 template <typename K, typename V>
-static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int sm_count, RoundPlan &rp)
+static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int sm_count, RoundPlan &rp, uint32_t leaf_bits = 0)
 {
 	using C = Cfg<K, V>;
 	constexpr uint64_t B = C::B, T = C::T;
@@ -223,7 +252,7 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 		Parent p;
 		p.start = s.start;
 		p.count = s.count;
-		p.width = pick_width(s.count, s.bits, small_max);
+		p.width = pick_width(s.count, s.bits, small_max, leaf_bits);
 		p.shift = s.bits - p.width;
 		p.child_base = rp.nchildren;
 		p.stripe_lo = (uint32_t)rp.stripes.size();
@@ -328,13 +357,11 @@ static int run_scan(msd_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n,
 
 // ------------------------------------------------------------------ the sort
 
-template <typename K, typename V> static uint64_t small_list_cap(uint64_t n)
+template <typename K, typename V> static uint64_t leaf_list_guess(uint64_t n)
 {
 	using C = Cfg<K, V>;
 	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
-	// children per round <= 6 n / small_max (pick_width); allow 2 rounds per key byte
-	const uint64_t cap = (uint64_t)(2 * sizeof(K)) * (6 * n / small_max + 512) + 16;
-	return std::min<uint64_t>(cap, n / 2 + 16);
+	return std::min<uint64_t>(n / 1024 + 6 * n / small_max + 4096, n / 2 + 16);
 }
 
 template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
@@ -342,8 +369,6 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 	Bump b(nullptr);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
 	b.take<Counters>(1);
-	b.take<Segment>(small_list_cap<K, V>(n) * 2); // general list (+ counting-sort fallbacks behind it)
-	b.take<Segment>(small_list_cap<K, V>(n));     // counting-sort list
 	return b.off + 4096;
 }
 
@@ -401,17 +426,16 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		cur.push_back({ 0, n, (uint32_t)end_bit, 0 });
 
 	// ---- buffers that live for the whole call
-	const uint64_t small_cap = small_list_cap<K, V>(n);
 	{
 		int rc = keep_reserve(c, keep_bytes_for<K, V>(n));
 		if (!rc) rc = pinned_reserve(c, 1 << 16);
+		if (!rc) rc = lists_reserve(c, 4096, 0, 0);
 		if (rc) return rc;
 	}
 	Bump kb(c->keep);
 	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
 	Counters *ctr = kb.take<Counters>(1);
-	Segment *small = kb.take<Segment>(small_cap * 2);
-	Segment *small_count = kb.take<Segment>(small_cap);
+	Segment *small = c->lists, *small_count = c->lists + 2 * c->lists_cap;
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 	// keys without payload whose last <= 16 bits are open are finished by the counting sort
 	const uint32_t count_bits = HV ? 0u : (uint32_t)kCountMaxBits;
@@ -428,7 +452,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	int round = 0;
 	while (!cur.empty()) {
 		RoundPlan rp;
-		plan_round<K, V>(cur, small_max, c->sm_count, rp);
+		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits);
 		if (single_pass) { // honour the caller's digit exactly
 			rp.parents[0].width = sp_width;
 			rp.parents[0].shift = sp_shift;
@@ -446,6 +470,13 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			carve_round<K, V>(b, rp, small_max, rb);
 		}
 		const uint32_t np = (uint32_t)rp.parents.size(), ns = (uint32_t)rp.stripes.size(), nc = rp.nchildren;
+		{ // every child of this round may become a leaf
+			int rc = lists_reserve(c, (size_t)std::max(nsmall_host, ncount_host) + nc + 16, nsmall_host, ncount_host);
+			if (rc) return rc;
+			small = c->lists;
+			small_count = c->lists + 2 * c->lists_cap;
+		}
+		const uint32_t small_cap = (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu);
 		if (round > 0) HIPCHK(c, hipMemsetAsync(ctr, 0, 3 * sizeof(uint32_t), c->stream)); // nholes, hole_cursor, next_parents
 		// ---- upload tables
 		{
@@ -499,7 +530,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				   rb.lo_off, rb.lo_dst, rb.ca, (const K *)rb.lo_keys, rb.lo_vals, keys, vals);
 		hipLaunchKernelGGL((excess_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, (const K *)rb.xkeys, rb.xvals, keys, vals);
 		hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, rb.parents, rb.ca,
-				   single_pass ? ~0ull : small_max, (uint32_t)small_cap, single_pass ? 0u : count_bits,
+				   single_pass ? ~0ull : small_max, small_cap, single_pass ? 0u : count_bits,
 				   rb.next_parents, small, small_count, ctr,
 				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr);
 		HIPCHK(c, hipGetLastError());
@@ -552,7 +583,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			HIPCHK(c, hipGetLastError());
 		}
 		if (ncount_host) { // counting-sort overflows (count only known on the device)
-			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(ncount_host), dim3(C::SORT_TH), sort_lds, c->stream,
+			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(std::min<uint32_t>(ncount_host, 2 * c->sm_count)), dim3(C::SORT_TH), sort_lds, c->stream,
 					   keys, vals, small + nsmall_host, 0u, (const uint32_t *)&ctr->nfallback);
 			HIPCHK(c, hipGetLastError());
 		}
@@ -560,7 +591,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 	set_stat(c, "count_segments", ncount_host);
 	set_stat(c, "small_segments", nsmall_host);
-	set_stat(c, "workspace_bytes", c->slab_bytes + c->keep_bytes);
+	set_stat(c, "workspace_bytes", c->slab_bytes + c->keep_bytes + 3 * c->lists_cap * sizeof(Segment));
 	phase_end(c);
 	return MSD_OK;
 }
@@ -618,6 +649,7 @@ int msd_destroy(msd_ctx *c)
 	(void)hipStreamSynchronize(c->stream);
 	if (c->slab) (void)hipFree(c->slab);
 	if (c->keep) (void)hipFree(c->keep);
+	if (c->lists) (void)hipFree(c->lists);
 	if (c->pinned) (void)hipHostFree(c->pinned);
 	if (c->ev_start) (void)hipEventDestroy(c->ev_start);
 	for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -636,25 +668,29 @@ int msd_reserve(msd_ctx *c, uint64_t n, int key_bytes, int val_bytes)
 {
 	if (!c) return MSD_EINVAL;
 	HIPCHK(c, hipSetDevice(c->device));
-	size_t round_b, keep_b;
+	size_t round_b, keep_b, list_n;
 	if (key_bytes == 4 && val_bytes == 0) {
 		round_b = round_bytes_estimate<uint32_t, NoVal>(n, c->sm_count);
 		keep_b = keep_bytes_for<uint32_t, NoVal>(n);
+		list_n = leaf_list_guess<uint32_t, NoVal>(n);
 	} else if (key_bytes == 8 && val_bytes == 0) {
 		round_b = round_bytes_estimate<uint64_t, NoVal>(n, c->sm_count);
 		keep_b = keep_bytes_for<uint64_t, NoVal>(n);
+		list_n = leaf_list_guess<uint64_t, NoVal>(n);
 	} else if (key_bytes == 8 && val_bytes == 8) {
 		round_b = round_bytes_estimate<uint64_t, uint64_t>(n, c->sm_count);
 		keep_b = keep_bytes_for<uint64_t, uint64_t>(n);
+		list_n = leaf_list_guess<uint64_t, uint64_t>(n);
 	} else
 		return fail(c, MSD_EINVAL, "unsupported element layout %d+%d bytes", key_bytes, val_bytes);
 	int rc = slab_reserve(c, round_b);
 	if (!rc) rc = keep_reserve(c, keep_b);
 	if (!rc) rc = pinned_reserve(c, 1 << 20);
+	if (!rc) rc = lists_reserve(c, list_n, 0, 0);
 	return rc;
 }
 
-uint64_t msd_workspace_bytes(const msd_ctx *c) { return c ? c->slab_bytes + c->keep_bytes : 0; }
+uint64_t msd_workspace_bytes(const msd_ctx *c) { return c ? c->slab_bytes + c->keep_bytes + 3 * c->lists_cap * sizeof(Segment) : 0; }
 const char *msd_last_error(const msd_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int msd_sort_u32_bits(msd_ctx *c, uint32_t *k, uint64_t n, int end_bit)

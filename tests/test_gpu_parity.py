@@ -63,6 +63,16 @@ def test_sort_u32_equals_oracle(ctx, n, kind):
     assert (host(t) == O.sort_u32(k)).all()
 
 
+@pytest.mark.parametrize("n", [1 << 22, (1 << 23) + 12345, 1 << 24, 3 << 23])
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "dup256"])
+def test_sort_u32_mid_sizes_equal_oracle(ctx, n, kind):
+    """Sizes where the round planner mixes digit widths (children of very different sizes)."""
+    k = make_u32(n, kind, seed=5)
+    t = dev(k)
+    ctx.sort_u32(t)
+    assert (host(t) == O.sort_u32(k)).all()
+
+
 def test_sort_u32_config_c1(ctx):
     """BASELINE.json configs[0]: 2^20 uniform u32; digest produced by the reference."""
     import hashlib

@@ -1,0 +1,49 @@
+"""Turns gpurun_out/<tag> (tools/profile_bench.sh) into the committed files under profiles/:
+   <round>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary of `python3 bench.py`
+   <round>_pmc_traffic.csv    FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes)
+   pmc_traffic.json           HBM bytes per launch per kernel, corrected as the MI355X guide prescribes
+                              (FETCH_SIZE reads 1/2 of a wide coalesced read stream on gfx950 -> x2; KiB units)
+   <round>_bench.json         the bench line of the same run
+"""
+import collections, csv, glob, json, os, shutil, sys
+tag, rnd = sys.argv[1], sys.argv[2]
+src = os.path.join("gpurun_out", tag)
+os.makedirs("profiles", exist_ok=True)
+st = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+shutil.copy(st, f"profiles/{rnd}_kernel_stats.csv")
+shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench.json")
+
+def short(name):
+    n = name.replace("void msd::", "").replace("msd::", "")
+    base = n.split("(")[0]
+    return base.replace("unsigned int, msd::NoVal", "u32").replace("unsigned long, msd::NoVal", "u64").replace("<64>", "<B64>").replace("unsigned long, unsigned long", "u64,u64").replace("unsigned int", "u32")
+
+acc = {}
+for ctr in ("fetch", "write"):
+    f = glob.glob(os.path.join(src, f"pmc_{ctr}", "**", "*counter_collection.csv"), recursive=True)[0]
+    per = collections.defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(f)):
+        k = short(row["Kernel_Name"])
+        per[k][0] += float(row["Counter_Value"])
+        per[k][1] += 1
+    acc[ctr] = per
+rows, js = [], {}
+for k in sorted(set(acc["fetch"]) | set(acc["write"])):
+    fv, fc = acc["fetch"].get(k, [0, 0]); wv, wc = acc["write"].get(k, [0, 0])
+    launches = max(fc, wc, 1)
+    fetch_b = fv * 1024 * 2 / launches      # gfx950: FETCH_SIZE counts 128-B requests as 64 B
+    write_b = wv * 1024 / launches
+    rows.append((k, launches, fv, wv, fetch_b, write_b))
+    js[k] = {"launches_profiled": launches, "hbm_read_bytes_per_launch": int(fetch_b), "hbm_write_bytes_per_launch": int(write_b),
+             "hbm_bytes_per_launch": int(fetch_b + write_b)}
+with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as o:
+    o.write("kernel,launches,FETCH_SIZE_sum_KiB_raw,WRITE_SIZE_sum_KiB,read_bytes_per_launch_corrected_x2,write_bytes_per_launch\n")
+    for r in rows:
+        o.write(",".join(str(x) for x in r) + "\n")
+json.dump(js, open("profiles/pmc_traffic.json", "w"), indent=1)
+for row in csv.DictReader(open(st)):
+    if float(row["Percentage"]) > 0.5:
+        print(f"{short(row['Name'])[:46]:46s} calls={row['Calls']:>4} avg_us={float(row['AverageNs'])/1e3:10.1f} pct={row['Percentage']}")
+for k, v in js.items():
+    if v["hbm_bytes_per_launch"] > 1e8:
+        print(f"{k[:46]:46s} HBM read {v['hbm_read_bytes_per_launch']/1e9:7.2f} GB  write {v['hbm_write_bytes_per_launch']/1e9:7.2f} GB per launch")
