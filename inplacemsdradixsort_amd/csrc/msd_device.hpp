@@ -43,15 +43,15 @@ template <> struct has_val<NoVal> { static constexpr bool value = false; };
 // blocks), T = elements per classify tile, TH = classify threads.
 template <typename K, typename V> struct Cfg;
 template <> struct Cfg<uint32_t, NoVal> {
-	static constexpr int B = 64, T = 2048, TH = 512;
+	static constexpr int B = 64, T = 4096, TH = 512;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 24; // LDS sort capacity 24576
 };
 template <> struct Cfg<uint64_t, NoVal> {
-	static constexpr int B = 32, T = 2048, TH = 512;
+	static constexpr int B = 32, T = 4096, TH = 512;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 12; // 12288
 };
 template <> struct Cfg<uint64_t, uint64_t> {
-	static constexpr int B = 32, T = 1024, TH = 256;
+	static constexpr int B = 32, T = 2048, TH = 256;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 6; // 6144
 };
 
@@ -173,12 +173,12 @@ template <> struct Vec16<uint64_t> { static constexpr int N = 2; };
 template <typename K, typename V> struct ClassifyLds {
 	using C = Cfg<K, V>;
 	static constexpr bool HV = has_val<V>::value;
-	static constexpr size_t kbuf = (size_t)(kP * C::B + C::T) * sizeof(K); // part | ost (contiguous)
-	static constexpr size_t vbuf = HV ? (size_t)(kP * C::B + C::T) * sizeof(uint64_t) : 0;
+	static constexpr size_t kbuf = (size_t)(kP * C::B) * sizeof(K); // per-bucket partial buffers
+	static constexpr size_t vbuf = HV ? (size_t)(kP * C::B) * sizeof(uint64_t) : 0;
 	static constexpr size_t head = (size_t)C::B * sizeof(K) + (HV ? (size_t)C::B * sizeof(uint64_t) : 0);
-	static constexpr int JOBS = kP + C::T / C::B + 8;
-	// meta, c, fbcnt, hc, loff : 5*kP u32 ; jobs ; tmp 8
-	static constexpr size_t small = (size_t)(5 * kP + JOBS + 8) * sizeof(uint32_t);
+	static constexpr int JOBS = kP + 8;
+	// meta, cnt, hc, loff : 4*kP u32 ; jobs ; tmp 16
+	static constexpr size_t small = (size_t)(4 * kP + JOBS + 16) * sizeof(uint32_t);
 	static constexpr size_t bytes = kbuf + vbuf + head + small;
 };
 
@@ -201,17 +201,16 @@ __global__ __launch_bounds__((Cfg<K, V>::TH)) void classify_kernel(
 	using L = ClassifyLds<K, V>;
 
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	K *kbuf = reinterpret_cast<K *>(smem); // [0,PB) partial buffers, [PB,PB+T) block staging
+	K *kbuf = reinterpret_cast<K *>(smem); // [0,PB) partial buffers
 	uint64_t *vbuf = reinterpret_cast<uint64_t *>(smem + L::kbuf);
 	K *headk = reinterpret_cast<K *>(smem + L::kbuf + L::vbuf);
 	uint64_t *headv = reinterpret_cast<uint64_t *>(smem + L::kbuf + L::vbuf + (size_t)B * sizeof(K));
 	uint32_t *meta = reinterpret_cast<uint32_t *>(smem + L::kbuf + L::vbuf + L::head);
 	uint32_t *cnt = meta + kP;   // tile count per bucket
-	uint32_t *fbcnt = cnt + kP;  // full blocks flushed per bucket
-	uint32_t *hc = fbcnt + kP;   // head keys per bucket
+	uint32_t *hc = cnt + kP;     // head keys per bucket
 	uint32_t *loff = hc + kP;    // leftover offsets
-	uint32_t *jobs = loff + kP;  // flush job table
-	uint32_t *tmp = jobs + L::JOBS;
+	uint32_t *jobs = loff + kP;  // flush job table: bucket whose buffer goes to slot wslot+g
+	uint32_t *tmp = jobs + L::JOBS; // [0..1] slots claimed per tile (ping-pong), [2..3] buffer-flush jobs, [4..] scan scratch
 
 	const uint32_t tid = threadIdx.x;
 	const Stripe st = stripes[blockIdx.x];
@@ -219,11 +218,11 @@ __global__ __launch_bounds__((Cfg<K, V>::TH)) void classify_kernel(
 	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u;
 
 	if (tid < kP) {
-		meta[tid] = 0; // fill=0, nb=0, obase=0
+		meta[tid] = 0;
 		cnt[tid] = 0;
-		fbcnt[tid] = 0;
 		hc[tid] = 0;
 	}
+	if (tid < 16) tmp[tid] = 0;
 	const uint64_t a0 = (uint64_t)st.slot_lo * B; // first aligned position >= begin
 	// ---- head keys (only a parent's first stripe has them): parked in LDS until the end
 	const uint32_t h = (uint32_t)((a0 < st.end ? a0 : st.end) - st.begin);
@@ -240,6 +239,12 @@ __global__ __launch_bounds__((Cfg<K, V>::TH)) void classify_kernel(
 
 	K kreg[KPT];
 	uint64_t vreg[HV ? KPT : 1];
+	// remainders of buckets flushed in the previous tile: written during this tile's scatter
+	K dkey[KPT];
+	uint64_t dval[HV ? KPT : 1];
+	uint32_t dat[KPT];
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) dat[i] = 0xFFFFFFFFu;
 
 	auto load_tile = [&](uint64_t pos, K *kr, uint64_t *vr) {
 #pragma unroll
@@ -270,114 +275,135 @@ __global__ __launch_bounds__((Cfg<K, V>::TH)) void classify_kernel(
 	};
 
 	uint64_t pos = a0;
-	K knext[KPT];
-	uint64_t vnext[HV ? KPT : 1];
-	if (pos < st.end) load_tile(pos, knext, vnext);
+	K kregB[KPT];
+	uint64_t vregB[HV ? KPT : 1];
+	if (pos < st.end) load_tile(pos, kreg, vreg);
+	if (pos + T < st.end) load_tile(pos + T, kregB, vregB);
+	uint32_t par = 0; // tile parity: which pair of claim counters is live
 
-	while (pos < st.end) {
-#pragma unroll
-		for (int i = 0; i < KPT; ++i) {
-			kreg[i] = knext[i];
-			if constexpr (HV) vreg[i] = vnext[i];
-		}
+	// One tile: [ranks] B1 [per-bucket bookkeeping] B2 [scatter] B3 [prefetch tile t+2 into the
+	// registers this tile just vacated] [flush].  Two register sets alternate (no copies), so a load
+	// is issued two tiles before its first use and, like the flush stores, a whole tile before the
+	// explicit vmcnt(0) (vmcnt counts loads and stores together).  The flush of tile t overlaps the
+	// rank phase of tile t+1; nothing it reads is written before B2 of tile t+1.
+	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1]) {
 		const uint64_t npos = pos + T;
-		if (npos < st.end) load_tile(npos, knext, vnext); // prefetch: original data beyond this tile
+		const bool full = npos <= st.end;                  // uniform: every key of the tile exists
 
-		// ---- rank every key inside its bucket for this tile
+		// ---- rank every key inside its bucket for this tile (LDS fetch-add)
 		uint32_t dr[KPT]; // digit | rank<<8
+		if (full) {
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) {
+				const uint32_t d = digit_of(kc[i], shift, mask);
+				dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
+			}
+		} else {
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) {
+				const uint64_t idx = pos + (uint64_t)((i / VEC) * TH + tid) * VEC + (i % VEC);
+				dr[i] = 0xFFFFFFFFu;
+				if (idx < st.end) {
+					const uint32_t d = digit_of(kc[i], shift, mask);
+					dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
+				}
+			}
+		}
+		__syncthreads(); // B1
+
+		// ---- per bucket: blocks completed by this tile claim consecutive output slots
+		if (tid < kP) {
+			const uint32_t L_r = fill_r + cnt[tid];
+			cnt[tid] = 0;
+			const uint32_t nb_r = L_r / B;
+			uint32_t bbase = 0;
+			if (nb_r) {
+				bbase = atomicAdd(&tmp[par], nb_r);            // slots wslot+bbase .. +nb_r-1
+				jobs[atomicAdd(&tmp[2 + par], 1u)] = tid | (bbase << 8); // the bucket's LDS buffer becomes block 0
+				for (uint32_t q = 1; q < nb_r; ++q) block_map[wslot + bbase + q] = (uint8_t)tid; // (skewed tiles only)
+			}
+			meta[tid] = fill_r | (nb_r << 8) | (bbase << 20);
+			fill_r = L_r - nb_r * B;
+			fb_r += nb_r;
+		}
+		if (tid == 0) { // the other parity's counters were last read before B1
+			tmp[par ^ 1] = 0;
+			tmp[2 + (par ^ 1)] = 0;
+		}
+		__syncthreads(); // B2
+		const uint32_t nbtot = tmp[par], njobs = tmp[2 + par];
+
+		// ---- scatter: first the remainders deferred from the previous tile, then this tile's keys
 #pragma unroll
 		for (int i = 0; i < KPT; ++i) {
-			const uint64_t idx = pos + (uint64_t)((i / VEC) * TH + tid) * VEC + (i % VEC);
-			if (idx < st.end) {
-				const uint32_t d = digit_of(kreg[i], shift, mask);
-				const uint32_t r = atomicAdd(&cnt[d], 1u);
-				dr[i] = d | (r << 8);
-			} else
-				dr[i] = 0xFFFFFFFFu;
+			if (dat[i] != 0xFFFFFFFFu) {
+				kbuf[dat[i]] = dkey[i];
+				if constexpr (HV) vbuf[dat[i]] = dval[i];
+				dat[i] = 0xFFFFFFFFu;
+			}
 		}
-		__syncthreads();
-
-		// ---- per bucket: how many blocks complete with this tile
-		uint32_t nb_r = 0, L_r = 0, pk = 0;
-		if (tid < kP) {
-			L_r = fill_r + cnt[tid];
-			nb_r = L_r / B;
-			pk = nb_r | ((nb_r ? nb_r - 1 : 0) << 16);
-		}
-		uint32_t tot;
-		const uint32_t ex = block_excl_scan256(pk, tmp, tot);
-		const uint32_t nbtot = tot & 0xFFFFu;
-		if (tid < kP) {
-			const uint32_t bbase = ex & 0xFFFFu, ob = ex >> 16; // ob in blocks
-			meta[tid] = fill_r | (nb_r << 8) | (ob << 20);
-			for (uint32_t q = 0; q < nb_r; ++q)
-				jobs[bbase + q] = (q == 0 ? tid * B : PB + (ob + q - 1) * B) | (tid << 24);
-		}
-		__syncthreads();
-
-		// ---- scatter: top up partial buffers, stage whole extra blocks, defer remainders
 #pragma unroll
 		for (int i = 0; i < KPT; ++i) {
 			if (dr[i] != 0xFFFFFFFFu) {
 				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
 				const uint32_t m = meta[d];
 				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
-				uint32_t at;
-				if (nb == 0 || vp < (uint32_t)B)
-					at = d * B + vp;
-				else if (vp < nb * B)
-					at = PB + (m >> 20) * B + (vp - B);
-				else
-					at = 0xFFFFFFFFu; // remainder of a flushed bucket: written after the flush
-				if (at != 0xFFFFFFFFu) {
-					kbuf[at] = kreg[i];
-					if constexpr (HV) vbuf[at] = vreg[i];
-					dr[i] = 0xFFFFFFFEu; // done
+				if (nb == 0 || vp < (uint32_t)B) { // tops up the bucket's buffer
+					kbuf[d * B + vp] = kc[i];
+					if constexpr (HV) vbuf[d * B + vp] = vc[i];
+				} else if (vp < nb * B) { // skewed tile: a further whole block of this bucket, straight to its slot
+					const uint64_t at = (uint64_t)(wslot + (m >> 20)) * B + vp;
+					keys[at] = kc[i];
+					if constexpr (HV) vals[at] = vc[i];
+				} else { // remainder of a flushed bucket: its buffer is still being flushed, park it
+					dat[i] = d * B + vp - nb * B;
+					dkey[i] = kc[i];
+					if constexpr (HV) dval[i] = vc[i];
 				}
 			}
 		}
-		__syncthreads();
+		__syncthreads(); // B3
 
-		// ---- flush nbtot blocks to consecutive slots behind the read cursor
-		for (uint32_t g = tid / LPB; g < nbtot; g += TH / LPB) {
+		// ---- everything outstanding is a tile old: drain it, then refill the vacated registers
+		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
+		if (npos + T < st.end) load_tile(npos + T, kc, vc);
+
+		// ---- flush the completed buffers to their slots behind the read cursor
+		for (uint32_t g = tid / LPB; g < njobs; g += TH / LPB) {
 			const uint32_t j = jobs[g];
-			const uint32_t src = (j & 0xFFFFFFu) + (tid % LPB) * VEC;
-			const uint64_t dst = (uint64_t)(wslot + g) * B + (tid % LPB) * VEC;
+			const uint32_t src = (j & 0xFFu) * B + (tid % LPB) * VEC;
+			const uint64_t dst = (uint64_t)(wslot + (j >> 8)) * B + (tid % LPB) * VEC;
 			*reinterpret_cast<uint4 *>(keys + dst) = *reinterpret_cast<const uint4 *>(kbuf + src);
 			if constexpr (HV)
 				*reinterpret_cast<uint4 *>(vals + dst) = *reinterpret_cast<const uint4 *>(vbuf + src);
-			if ((tid % LPB) == 0) block_map[wslot + g] = (uint8_t)(j >> 24);
-		}
-		__syncthreads();
-
-		// ---- deferred remainders go to the front of their (now empty) buffer
-#pragma unroll
-		for (int i = 0; i < KPT; ++i) {
-			if (dr[i] < 0xFFFFFFFEu) {
-				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
-				const uint32_t m = meta[d];
-				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
-				kbuf[d * B + vp - nb * B] = kreg[i];
-				if constexpr (HV) vbuf[d * B + vp - nb * B] = vreg[i];
-			}
-		}
-		if (tid < kP) {
-			fill_r = L_r - nb_r * B;
-			fb_r += nb_r;
-			cnt[tid] = 0;
+			if ((tid % LPB) == 0) block_map[wslot + (j >> 8)] = (uint8_t)(j & 0xFFu);
 		}
 		wslot += nbtot;
 		pos = npos;
-		__syncthreads();
-		if (tid < kP) meta[tid] = fill_r; // keeps meta coherent for the final write-out
+		par ^= 1;
+	};
+	while (pos < st.end) {
+		tile(kreg, vreg);
+		if (pos >= st.end) break;
+		tile(kregB, vregB);
 	}
+	__syncthreads();
+	// remainders deferred by the last tile
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) {
+		if (dat[i] != 0xFFFFFFFFu) {
+			kbuf[dat[i]] = dkey[i];
+			if constexpr (HV) vbuf[dat[i]] = dval[i];
+		}
+	}
+	if (tid < kP) meta[tid] = fill_r;
 	__syncthreads();
 
 	// ---- stripe epilogue: leftovers (partial buffers + head keys) to the side area
 	uint32_t lc = 0;
 	if (tid < kP) lc = fill_r + hc[tid];
 	uint32_t ltot;
-	const uint32_t lex = block_excl_scan256(lc, tmp, ltot);
+	const uint32_t lex = block_excl_scan256(lc, tmp + 4, ltot);
 	const size_t so = (size_t)blockIdx.x * kP + tid;
 	if (tid < kP) {
 		loff[tid] = lex;
