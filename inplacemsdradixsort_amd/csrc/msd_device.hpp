@@ -43,7 +43,7 @@ template <> struct has_val<NoVal> { static constexpr bool value = false; };
 // blocks), T = elements per classify tile, TH = classify threads.
 template <typename K, typename V> struct Cfg;
 template <> struct Cfg<uint32_t, NoVal> {
-	static constexpr int B = 64, T = 4096, TH = 512;
+	static constexpr int B = 64, T = 4096, TH = 1024;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 24; // LDS sort capacity 24576
 };
 template <> struct Cfg<uint64_t, NoVal> {
@@ -183,7 +183,7 @@ template <typename K, typename V> struct ClassifyLds {
 };
 
 template <typename K, typename V>
-__global__ __launch_bounds__((Cfg<K, V>::TH)) void classify_kernel(
+__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) void classify_kernel(
 	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, uint8_t *__restrict__ block_map,
 	uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt, uint32_t *__restrict__ lo_off,
@@ -1247,6 +1247,33 @@ __global__ __launch_bounds__(kScanTh) void scan_lookback_kernel(const uint64_t *
 	for (int i = 0; i < kScanIpt; ++i) {
 		if (base + i < n) out[base + i] = run;
 		run += v[i];
+	}
+}
+
+// ------------------------------------------------- varying-bit reduction
+
+// OR and AND over keys[0], keys[stride], keys[2*stride], ...: bits where OR and AND differ
+// vary somewhere in the (sampled) input.  res[0] |= OR, res[1] &= AND (res preset to 0 / ~0).
+template <typename K>
+__global__ __launch_bounds__(256) void vary_kernel(const K *__restrict__ keys, uint64_t n, uint64_t stride,
+	unsigned long long *__restrict__ res)
+{
+	K o = 0, a = ~(K)0;
+	const uint64_t cnt = (n + stride - 1) / stride;
+	const uint64_t step = (uint64_t)gridDim.x * 256;
+	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += step) {
+		const K k = keys[i * stride];
+		o |= k;
+		a &= k;
+	}
+#pragma unroll
+	for (int s = 32; s > 0; s >>= 1) {
+		o |= __shfl_xor(o, s);
+		a &= __shfl_xor(a, s);
+	}
+	if (lane_id() == 0) {
+		atomicOr(&res[0], (unsigned long long)o);
+		atomicAnd(&res[1], (unsigned long long)a | (sizeof(K) == 4 ? 0xFFFFFFFF00000000ull : 0ull));
 	}
 }
 

@@ -234,7 +234,8 @@ static uint32_t pick_width(uint64_t count, uint32_t bits, uint64_t small_max, ui
 }
 
 template <typename K, typename V>
-static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int sm_count, RoundPlan &rp, uint32_t leaf_bits = 0)
+static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int sm_count, RoundPlan &rp, uint32_t leaf_bits = 0,
+		       uint32_t forced_width = 0)
 {
 	using C = Cfg<K, V>;
 	constexpr uint64_t B = C::B, T = C::T;
@@ -252,7 +253,7 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 		Parent p;
 		p.start = s.start;
 		p.count = s.count;
-		p.width = pick_width(s.count, s.bits, small_max, leaf_bits);
+		p.width = forced_width ? forced_width : pick_width(s.count, s.bits, small_max, leaf_bits);
 		p.shift = s.bits - p.width;
 		p.child_base = rp.nchildren;
 		p.stripe_lo = (uint32_t)rp.stripes.size();
@@ -273,8 +274,8 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 			if (st.slot_hi < st.slot_lo) st.slot_hi = st.slot_lo;
 			st.lo_base = rp.lo_elems;
 			st.pad = 0;
-			// leftovers: < B per bucket from the stream, plus < B head keys
-			rp.lo_elems += std::min<uint64_t>(e - b, (uint64_t)kP * (B - 1) + B);
+			// leftovers: < B per bucket (2^width buckets) from the stream, plus < B head keys
+			rp.lo_elems += std::min<uint64_t>(e - b, ((uint64_t)1 << p.width) * (B - 1) + B);
 			rp.nslots += st.slot_hi - st.slot_lo;
 			rp.stripes.push_back(st);
 			b = e;
@@ -368,7 +369,7 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 {
 	Bump b(nullptr);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
-	b.take<Counters>(1);
+	b.take<Counters>(2); // counters + scratch for the varying-bit reduction
 	return b.off + 4096;
 }
 
@@ -434,11 +435,51 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 	Bump kb(c->keep);
 	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
-	Counters *ctr = kb.take<Counters>(1);
+	Counters *ctr = kb.take<Counters>(2);
 	Segment *small = c->lists, *small_count = c->lists + 2 * c->lists_cap;
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 	// keys without payload whose last <= 16 bits are open are finished by the counting sort
 	const uint32_t count_bits = HV ? 0u : (uint32_t)kCountMaxBits;
+
+	// ---- leading-bit skipping: a cheap strided sample decides whether an exact OR/AND pass over
+	// all keys can pay off (it does when whole leading digits are constant, e.g. keys whose upper
+	// half is zero); all-equal inputs are finished here.
+	if (!single_pass && !cur.empty() && n >= 4096) {
+		unsigned long long *vres = reinterpret_cast<unsigned long long *>(ctr + 1);
+		auto run_vary = [&](uint64_t stride, uint64_t *vary_out) -> int {
+			const unsigned long long init[2] = { 0ull, ~0ull };
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			memcpy(c->pinned, init, sizeof init);
+			HIPCHK(c, hipMemcpyAsync(vres, c->pinned, sizeof init, hipMemcpyHostToDevice, c->stream));
+			const uint64_t cnt = (n + stride - 1) / stride;
+			const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (cnt + 255) / 256);
+			hipLaunchKernelGGL((vary_kernel<K>), dim3(grid), dim3(256), 0, c->stream, keys, n, stride, vres);
+			HIPCHK(c, hipGetLastError());
+			HIPCHK(c, hipMemcpyAsync(c->pinned, vres, sizeof init, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			const unsigned long long *h = (const unsigned long long *)c->pinned;
+			*vary_out = h[0] ^ h[1];
+			return MSD_OK;
+		};
+		const uint64_t low_mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+		uint64_t vary = 0;
+		int rc = run_vary(std::max<uint64_t>(1, n / 8192), &vary);
+		if (rc) return rc;
+		vary &= low_mask;
+		const int top_sample = vary ? 64 - __builtin_clzll(vary) : 0;
+		if (top_sample + 8 <= end_bit) { // at least one whole leading digit looks constant: make sure
+			rc = run_vary(1, &vary);
+			if (rc) return rc;
+			vary &= low_mask;
+			const int top = vary ? 64 - __builtin_clzll(vary) : 0;
+			set_stat(c, "skipped_bits", (uint64_t)(end_bit - top));
+			if (top == 0)
+				cur.clear(); // every key is the same on the bits in question: already sorted
+			else
+				cur[0].bits = (uint32_t)top;
+		}
+		phase_mark(c, "bit skip");
+	}
 
 	uint32_t nsmall_host = 0, ncount_host = 0;
 	if (!single_pass && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
@@ -452,12 +493,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	int round = 0;
 	while (!cur.empty()) {
 		RoundPlan rp;
-		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits);
-		if (single_pass) { // honour the caller's digit exactly
-			rp.parents[0].width = sp_width;
-			rp.parents[0].shift = sp_shift;
-			rp.nchildren = 1u << sp_width;
-		}
+		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits, single_pass ? sp_width : 0u);
 		RoundBufs rb;
 		{
 			Bump sz(nullptr);
