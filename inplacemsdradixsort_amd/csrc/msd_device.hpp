@@ -449,36 +449,55 @@ struct ChildArrays {
 };
 
 template <int B>
-__global__ __launch_bounds__(256) void child_scan_kernel(const Parent *__restrict__ parents,
+__global__ __launch_bounds__(1024) void child_scan_kernel(const Parent *__restrict__ parents,
 	const uint32_t *__restrict__ fb, const uint32_t *__restrict__ lo_cnt,
 	uint32_t *__restrict__ lo_dst, ChildArrays ca)
 {
+	// thread (g, d): stripe group g of 4 walks a contiguous quarter of the parent's stripes for bucket d
 	__shared__ uint64_t tmp[8];
+	__shared__ uint32_t gF[4][kP], gL[4][kP];
 	const Parent pa = parents[blockIdx.x];
-	const uint32_t d = threadIdx.x;
-	uint64_t F = 0, ls = 0;
+	const uint32_t d = threadIdx.x & 255, g = threadIdx.x >> 8;
+	const uint32_t ns = pa.stripe_hi - pa.stripe_lo, per = (ns + 3) / 4;
+	const uint32_t s0 = pa.stripe_lo + g * per, s1 = s0 + per < pa.stripe_hi ? s0 + per : pa.stripe_hi;
+	uint32_t F = 0, ls = 0;
 #pragma unroll 8
-	for (uint32_t s = pa.stripe_lo; s < pa.stripe_hi; ++s) {
+	for (uint32_t s = s0; s < s1; ++s) {
 		const size_t o = (size_t)s * kP + d;
 		F += fb[o];
-		lo_dst[o] = (uint32_t)ls;
 		ls += lo_cnt[o];
 	}
-	const uint64_t c = F * B + ls;
+	gF[g][d] = F;
+	gL[g][d] = ls;
+	__syncthreads();
+	uint32_t pre = 0;
+	for (uint32_t gg = 0; gg < g; ++gg) pre += gL[gg][d];
+#pragma unroll 8
+	for (uint32_t s = s0; s < s1; ++s) { // second walk: where each stripe's leftovers go inside the child
+		const size_t o = (size_t)s * kP + d;
+		lo_dst[o] = pre;
+		pre += lo_cnt[o];
+	}
+	uint64_t Ft = 0, lt = 0, c = 0;
+	if (g == 0) {
+		Ft = (uint64_t)gF[0][d] + gF[1][d] + gF[2][d] + gF[3][d];
+		lt = (uint64_t)gL[0][d] + gL[1][d] + gL[2][d] + gL[3][d];
+		c = Ft * B + lt;
+	}
 	uint64_t total;
 	const uint64_t ex = block_excl_scan256_64(c, tmp, total);
-	if (d < (1u << pa.width)) {
+	if (g == 0 && d < (1u << pa.width)) {
 		const uint32_t ci = pa.child_base + d;
 		const uint64_t st = pa.start + ex, en = st + c;
 		const uint64_t is = (st + B - 1) / B, ie = en / B;
 		const uint64_t room = ie > is ? ie - is : 0;
-		const uint64_t I = F < room ? F : room;
+		const uint64_t I = Ft < room ? Ft : room;
 		ca.start[ci] = st;
 		ca.count[ci] = c;
-		ca.F[ci] = (uint32_t)F;
+		ca.F[ci] = (uint32_t)Ft;
 		ca.is[ci] = (uint32_t)is;
 		ca.I[ci] = (uint32_t)I;
-		ca.lsum[ci] = (uint32_t)ls;
+		ca.lsum[ci] = (uint32_t)lt;
 		ca.n_int[ci] = 0;
 		ca.n_fr[ci] = 0;
 		ca.cur_int[ci] = 0;
@@ -606,45 +625,43 @@ __device__ __forceinline__ T *slot_ptr(T *base, T *xbase, uint32_t slot)
 	return slot < kXBase ? base + (uint64_t)slot * B : xbase + (uint64_t)(slot - kXBase) * B;
 }
 
-// One wave per child that needs it: (a) evict one interior-class block to the side
-// store so that the child's list ends with a chain-terminating entry, (b) open the
-// virtual slot that takes the child's excess block.
+// One thread per child; the rare child that needs it (a) evicts one interior-class block to
+// the side store so that its list ends with a chain-terminating entry, (b) opens the virtual
+// slot that takes its excess block.
 template <typename K, typename V>
-__global__ __launch_bounds__(64) void evict_kernel(uint32_t nchildren, ChildArrays ca,
+__global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArrays ca,
 	ListEntry *__restrict__ list, ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
 	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals)
 {
 	constexpr int B = Cfg<K, V>::B;
 	constexpr bool HV = has_val<V>::value;
-	const uint32_t ci = blockIdx.x;
+	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
 	if (ci >= nchildren) return;
 	const uint32_t fl = ca.flags[ci];
 	if (fl == 0) return;
-	const uint32_t lane = threadIdx.x;
 	if (fl & 1u) {
 		const uint64_t e = ca.list_base[ci] + ca.n_int0[ci] - 1;
 		const ListEntry ent = list[e];
 		const uint32_t xs = kXBase + 2 * ci;
-		for (uint32_t j = lane; j < (uint32_t)B; j += 64) {
-			slot_ptr<K, B>(keys, xkeys, xs)[j] = slot_ptr<K, B>(keys, xkeys, ent.slot)[j];
-			if constexpr (HV)
-				slot_ptr<uint64_t, B>(vals, xvals, xs)[j] = slot_ptr<uint64_t, B>(vals, xvals, ent.slot)[j];
+		K *dk = slot_ptr<K, B>(keys, xkeys, xs);
+		const K *sk = slot_ptr<K, B>(keys, xkeys, ent.slot);
+		for (int j = 0; j < B; ++j) dk[j] = sk[j];
+		if constexpr (HV) {
+			uint64_t *dv = slot_ptr<uint64_t, B>(vals, xvals, xs);
+			const uint64_t *sv = slot_ptr<uint64_t, B>(vals, xvals, ent.slot);
+			for (int j = 0; j < B; ++j) dv[j] = sv[j];
 		}
-		if (lane == 0) {
-			ListEntry ne;
-			ne.slot = xs;
-			ne.owner = kNoOwner;
-			list[e] = ne;
-			const uint32_t p = atomicAdd(&ctr->nholes, 1u);
-			holes[p] = ent; // the vacated slot, owned by the interior it lies in
-		}
+		ListEntry ne;
+		ne.slot = xs;
+		ne.owner = kNoOwner;
+		list[e] = ne;
+		holes[atomicAdd(&ctr->nholes, 1u)] = ent; // the vacated slot, owned by the interior it lies in
 	}
-	if ((fl & 2u) && lane == 0) {
-		const uint32_t p = atomicAdd(&ctr->nholes, 1u);
+	if (fl & 2u) {
 		ListEntry hsl;
 		hsl.slot = kXBase + 2 * ci + 1;
 		hsl.owner = ci;
-		holes[p] = hsl;
+		holes[atomicAdd(&ctr->nholes, 1u)] = hsl;
 	}
 }
 
@@ -1063,8 +1080,17 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 
 	uint32_t *mycnt = wcnt + w * kP;
 	bool in_lds = false;
-	for (uint32_t shift = 0; shift < sg.bits; shift += 8) {
-		const uint32_t width = sg.bits - shift < 8 ? sg.bits - shift : 8;
+	// With many open bits (u64 keys) few of them are needed to tell <= CAP keys apart: sort on the
+	// TOP 16 open bits only (2 stable passes), then put the few groups of equal top bits in order
+	// by comparing whole keys.  Falls through to the remaining low passes if a group is too long.
+	const K openmask = sg.bits >= sizeof(K) * 8 ? ~(K)0 : (((K)1 << sg.bits) - 1);
+	const K vopen = vary & openmask;
+	// bits above the highest varying one need no pass at all
+	const uint32_t nbits = vopen ? (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen)) : 0u;
+	const uint32_t first_shift = nbits > 24 ? nbits - 16 : 0;
+	bool msd_mode = first_shift != 0;
+	for (uint32_t shift = first_shift; shift < nbits; shift += 8) {
+		const uint32_t width = nbits - shift < 8 ? nbits - shift : 8;
 		const uint32_t mask = (1u << width) - 1u;
 		if (((uint32_t)(vary >> shift) & mask) == 0) continue; // digit constant over the segment
 		for (uint32_t j = tid; j < NW * kP; j += TH) wcnt[j] = 0;
@@ -1120,9 +1146,50 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void lds_sort_kernel(K *__res
 		in_lds = true;
 		// is there another pass with a varying digit?
 		bool more = false;
-		for (uint32_t s2 = shift + 8; s2 < sg.bits; s2 += 8) {
-			const uint32_t w2 = sg.bits - s2 < 8 ? sg.bits - s2 : 8;
+		for (uint32_t s2 = shift + 8; s2 < nbits; s2 += 8) {
+			const uint32_t w2 = nbits - s2 < 8 ? nbits - s2 : 8;
 			if (((uint32_t)(vary >> s2) & ((1u << w2) - 1u)) != 0) more = true;
+		}
+		if (!more && msd_mode) {
+			// ---- groups of equal top bits: the first element of each group orders it by whole keys
+			const K lowmask = ((K)1 << first_shift) - 1;
+			if (tid == 0) tmp[0] = 0;
+			__syncthreads();
+			bool too_long = false;
+			if ((vary & lowmask) != 0) {
+				for (uint32_t i = tid; i < n; i += TH) {
+					const K hi = xk[i] >> first_shift;
+					if ((i == 0 || (xk[i - 1] >> first_shift) != hi) && i + 1 < n && (xk[i + 1] >> first_shift) == hi) {
+						uint32_t e = i + 2;
+						while (e < n && (xk[e] >> first_shift) == hi) ++e;
+						if (e - i > 48) {
+							too_long = true;
+						} else {
+							for (uint32_t a = i + 1; a < e; ++a) { // insertion sort of [i, e)
+								const K ka = xk[a];
+								uint64_t va = 0;
+								if constexpr (HV) va = xv[a];
+								uint32_t b = a;
+								while (b > i && xk[b - 1] > ka) {
+									xk[b] = xk[b - 1];
+									if constexpr (HV) xv[b] = xv[b - 1];
+									--b;
+								}
+								xk[b] = ka;
+								if constexpr (HV) xv[b] = va;
+							}
+						}
+					}
+				}
+			}
+			if (too_long) tmp[0] = 1;
+			__syncthreads();
+			if (tmp[0]) { // rare: redo as a plain LSD sort over all open bits, starting from the current order
+				msd_mode = false;
+				more = true;
+				shift = (uint32_t)0 - 8u; // the loop increment brings it to 0
+			}
+			__syncthreads();
 		}
 		if (!more) break;
 #pragma unroll

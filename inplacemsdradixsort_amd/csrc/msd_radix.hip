@@ -536,7 +536,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		phase_mark(c, "A classify");
 
 		// ---- block metadata: child geometry, misplaced-block lists, holes
-		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(256), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
+		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(1024), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
 		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr);
 		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca);
@@ -546,7 +546,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr);
-		hipLaunchKernelGGL((evict_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
+		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
 				   keys, vals, (K *)rb.xkeys, rb.xvals);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "B metadata");

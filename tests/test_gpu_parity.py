@@ -115,6 +115,28 @@ def test_sort_u64_equals_oracle(ctx, n, kind):
     assert (host(t) == O.sort_u64(k)).all()
 
 
+@pytest.mark.parametrize("kind", ["lowvary", "groups", "twolevel"])
+@pytest.mark.parametrize("n", [3000, 12288, 200000])
+def test_sort_u64_msd_leaf_paths(ctx, n, kind):
+    """u64 leaves with many open bits: top-16-bit LDS passes + group fix-up, its long-group
+    fallback, and constant leading digits."""
+    rng = np.random.default_rng(n)
+    if kind == "lowvary":      # only the low 20 bits vary: leading digits of the open range are constant
+        k = rng.integers(0, 1 << 20, n, dtype=np.uint64) | np.uint64(0x00AB000000000000)
+    elif kind == "groups":     # few distinct top parts, long runs that differ only in low bits (fallback)
+        k = (rng.integers(0, 40, n, dtype=np.uint64) << np.uint64(44)) | rng.integers(0, 1 << 30, n, dtype=np.uint64)
+    else:                      # random top, tiny random bottom: many short groups
+        k = (rng.integers(0, 1 << 12, n, dtype=np.uint64) << np.uint64(50)) | rng.integers(0, 4, n, dtype=np.uint64)
+    t = dev(k)
+    ctx.sort_u64(t)
+    assert (host(t) == np.sort(k)).all()
+    r = np.arange(n, dtype=np.uint64)
+    tk, tr = dev(k), dev(r)
+    ctx.sort_pairs_u64(tk, tr)
+    ko, ro = host(tk), host(tr)
+    assert (ko == np.sort(k)).all() and (k[ro] == ko).all() and (np.sort(ro) == r).all()
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 21, 6144, 6145, 50001, 1 << 19, (1 << 21) + 3])
 @pytest.mark.parametrize("kind", ["full", "hi32zero", "dup"])
 def test_sort_pairs_parity(ctx, n, kind):
