@@ -109,6 +109,25 @@ int msd_gen_uniform_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, uint64_t see
 int msd_gen_zipf_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t seed, uint64_t first);
 int msd_gen_iota_u64(msd_ctx *ctx, uint64_t *d_vals, uint64_t n, uint64_t first);
 
+/* ---- pass planner (reference: schedule_passes(), src/msb_64.c:1334-1400) -------------
+ * Host-only (no device needed).  The reference plans 1-3 leading passes of <= 9 bits
+ * to reach <= 6500-tuple pieces; this planner cuts segments by <= 8-bit digits until they
+ * fit the LDS leaf sorters.  Describes the FIRST round for n elements with `end_bit`
+ * open key bits; later rounds depend on the data and are planned from the child counts. */
+typedef struct msd_plan {
+	uint32_t digit_width;      /* bits of the first digit (0: no partition round, LDS leaf only) */
+	uint32_t digit_shift;      /* digit = (key >> digit_shift) & (2^digit_width - 1) */
+	uint32_t block_elems;      /* elements per 256-byte block */
+	uint32_t tile_elems;       /* elements per classify tile */
+	uint64_t stripe_elems;     /* elements per stripe (one classify workgroup) */
+	uint64_t stripes;          /* stripes of the first round */
+	uint64_t leaf_capacity;    /* largest segment the LDS leaf sorter takes */
+	uint32_t leaf_count_bits;  /* open bits the one-pass counting leaf can finish (0: not used) */
+	uint32_t expected_rounds;  /* rounds for uniformly distributed keys */
+	uint64_t workspace_bytes;  /* per-round + per-call auxiliary memory for this shape */
+} msd_plan;
+int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, int compute_units, msd_plan *out);
+
 /* ---- phase report (reference: description[]/times[], src/msb_64.c:2402-2412) */
 
 /* Enable per-phase hipEvent timing for subsequent sorts on this context

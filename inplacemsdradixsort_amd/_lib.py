@@ -21,11 +21,19 @@ EXPORTS = [
     "msd_partition_u32", "msd_partition_u64", "msd_partition_pairs_u64",
     "msd_check_u32", "msd_check_u64",
     "msd_gen_uniform_u32", "msd_gen_uniform_u64", "msd_gen_zipf_u32", "msd_gen_iota_u64",
+    "msd_plan_first_round",
     "msd_set_profiling", "msd_phase_count", "msd_phase_name", "msd_phase_us", "msd_stat",
     "sort", "mamalloc", "check",
 ]
 
 _lib = None
+
+
+class MsdPlan(C.Structure):
+    _fields_ = [("digit_width", C.c_uint32), ("digit_shift", C.c_uint32), ("block_elems", C.c_uint32),
+                ("tile_elems", C.c_uint32), ("stripe_elems", C.c_uint64), ("stripes", C.c_uint64),
+                ("leaf_capacity", C.c_uint64), ("leaf_count_bits", C.c_uint32), ("expected_rounds", C.c_uint32),
+                ("workspace_bytes", C.c_uint64)]
 
 _vp = C.c_void_p
 _u64 = C.c_uint64
@@ -72,6 +80,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.msd_gen_uniform_u64.argtypes = [_vp, _vp, _u64, _u64, _u64, C.c_int]
     L.msd_gen_zipf_u32.argtypes = [_vp, _vp, _u64, _u64, _u64]
     L.msd_gen_iota_u64.argtypes = [_vp, _vp, _u64, _u64]
+    L.msd_plan_first_round.argtypes = [_u64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MsdPlan)]
     L.msd_set_profiling.argtypes = [_vp, C.c_int]
     L.msd_phase_count.argtypes = [_vp]
     L.msd_phase_name.argtypes = [_vp, C.c_int]

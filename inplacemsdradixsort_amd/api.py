@@ -155,6 +155,19 @@ class MsdContext:
         return out
 
 
+def plan_first_round(n: int, key_bytes: int = 4, val_bytes: int = 0, end_bit: Optional[int] = None,
+                     compute_units: int = 256) -> Dict[str, int]:
+    """Host-only pass planner (the counterpart of the reference's schedule_passes,
+    src/msb_64.c:1334-1400); needs no GPU."""
+    L = _lib.load()
+    p = _lib.MsdPlan()
+    rc = L.msd_plan_first_round(n, key_bytes, val_bytes, key_bytes * 8 if end_bit is None else end_bit,
+                                compute_units, C.byref(p))
+    if rc != 0:
+        raise MsdError(f"msd_plan_first_round failed with {rc}")
+    return {f: int(getattr(p, f)) for f, _ in p._fields_}
+
+
 # ---------------------------------------------------------------------------
 # the reference's own surface, on host numpy arrays
 # ---------------------------------------------------------------------------

@@ -873,6 +873,54 @@ int msd_gen_iota_u64(msd_ctx *c, uint64_t *v, uint64_t n, uint64_t first)
 	return MSD_OK;
 }
 
+} // extern "C"
+
+template <typename K, typename V>
+static int plan_describe(uint64_t n, int end_bit, int cus, msd_plan *out)
+{
+	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
+	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
+	const uint32_t count_bits = HV ? 0u : (uint32_t)kCountMaxBits;
+	memset(out, 0, sizeof *out);
+	out->block_elems = C::B;
+	out->tile_elems = C::T;
+	out->leaf_capacity = small_max;
+	out->leaf_count_bits = count_bits;
+	if (n <= small_max || end_bit <= 0) return MSD_OK; // a single LDS leaf
+	std::vector<Segment> segs(1);
+	segs[0] = { 0, n, (uint32_t)end_bit, 0 };
+	RoundPlan rp;
+	plan_round<K, V>(segs, small_max, cus, rp, count_bits);
+	out->digit_width = rp.parents[0].width;
+	out->digit_shift = rp.parents[0].shift;
+	out->stripes = rp.stripes.size();
+	out->stripe_elems = rp.stripes[0].end - rp.stripes[0].begin;
+	// uniform keys: every round divides the segment size by 2^width
+	uint64_t sz = n;
+	uint32_t bits = (uint32_t)end_bit, rounds = 0;
+	while (sz > small_max && bits > 0) {
+		const uint32_t w = pick_width(sz, bits, small_max, count_bits);
+		sz >>= w;
+		bits -= w;
+		++rounds;
+	}
+	out->expected_rounds = rounds;
+	out->workspace_bytes = round_bytes_estimate<K, V>(n, cus) + keep_bytes_for<K, V>(n) + 3 * leaf_list_guess<K, V>(n) * sizeof(Segment);
+	return MSD_OK;
+}
+
+extern "C" {
+
+int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, int cus, msd_plan *out)
+{
+	if (!out || cus <= 0 || end_bit < 0 || end_bit > key_bytes * 8) return MSD_EINVAL;
+	if (key_bytes == 4 && val_bytes == 0) return plan_describe<uint32_t, NoVal>(n, end_bit, cus, out);
+	if (key_bytes == 8 && val_bytes == 0) return plan_describe<uint64_t, NoVal>(n, end_bit, cus, out);
+	if (key_bytes == 8 && val_bytes == 8) return plan_describe<uint64_t, uint64_t>(n, end_bit, cus, out);
+	return MSD_EINVAL;
+}
+
 int msd_set_profiling(msd_ctx *c, int on)
 {
 	if (!c) return MSD_EINVAL;
