@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--logn", type=int, default=30, help="log2 keys per GPU (default 30 = BASELINE config)")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logn", type=int, default=27)
+    ap.add_argument("--cpu-logn", type=int, default=29, help="log2 keys of the CPU-baseline sample (2^29: ~13 s of one core)")
     return ap.parse_args()
 
 

@@ -16,7 +16,10 @@ shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench.json")
 def short(name):
     n = name.replace("void msd::", "").replace("msd::", "")
     base = n.split("(")[0]
-    return base.replace("unsigned int, msd::NoVal", "u32").replace("unsigned long, msd::NoVal", "u64").replace("<64>", "<B64>").replace("unsigned long, unsigned long", "u64,u64").replace("unsigned int", "u32")
+    for old, new in (("unsigned int, NoVal", "u32"), ("unsigned long, NoVal", "u64"),
+                     ("unsigned long, unsigned long", "u64,u64"), ("unsigned int", "u32"), ("unsigned long", "u64")):
+        base = base.replace(old, new)
+    return base
 
 acc = {}
 for ctr in ("fetch", "write"):
