@@ -47,11 +47,12 @@ def parse():
     ap.add_argument("--logn", type=int, default=30, help="log2 keys per GPU (default 30 = BASELINE config)")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-logn", type=int, default=29, help="log2 keys of the CPU-baseline sample (2^29: ~13 s of one core)")
+    ap.add_argument("--cpu-logn", type=int, default=28, help="log2 tuples for the reference's 64-thread sort()")
+    ap.add_argument("--cpu-logn-1t", type=int, default=27, help="log2 keys for the single-thread core")
     return ap.parse_args()
 
 
-def cpu_baseline(logn: int):
+def cpu_baseline_single(logn: int):
     """The reference's single-thread core (schedule_passes + local_radixsort,
     src/msb_64.c:2232-2244) from oracle/_ref, timed on this host; falls back to the
     C restatement ("port") if the prebuilt reference is absent."""
@@ -59,7 +60,6 @@ def cpu_baseline(logn: int):
     from oracle import oracle as O
     n = 1 << logn
     k32 = O.gen_uniform_u32(n, seed=0x5EED0001)
-    cores = 1
     if O.have_ref():
         k = O.aligned(n)
         r = O.aligned(n)
@@ -77,11 +77,43 @@ def cpu_baseline(logn: int):
         ok = bool((np.diff(k32.astype(np.int64)) >= 0).all())
         kind = "port"
     return {
-        "value": round(n / dt / 1e9, 5), "unit": "Gkeys/s", "cores": cores, "kind": kind,
+        "value": round(n / dt / 1e9, 5), "unit": "Gkeys/s", "cores": 1, "kind": kind,
         "sample": f"2^{logn} uniform u32 keys (zero-extended to u64, rid=key, bits=32), "
                   f"single-thread schedule_passes+local_radixsort, {dt:.2f} s, output verified={ok}, "
                   f"host has {os.cpu_count()} logical cpus",
     }
+
+
+def cpu_baseline(logn_mt: int, logn_1t: int):
+    """CPU baseline beside the GPU number: the reference's own pthreads sort() (src/msb_64.c:2261,
+    64 threads as it demands) from oracle/_ref, run in a subprocess (the reference is fragile,
+    SURVEY.md section 0.9) and verified; if it is absent, crashes or fails verification, the
+    reference's single-thread core is reported instead."""
+    import subprocess
+    single = cpu_baseline_single(logn_1t)
+    script = os.path.join(ROOT, "oracle", "ref_sort_mt.py")
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libref_msb64.so")
+    note = "oracle/_ref absent"
+    if os.path.exists(ref_lib):
+        try:
+            p = subprocess.run([sys.executable, script, str(logn_mt), "2", "3"], capture_output=True, text=True, timeout=420)
+            if p.returncode == 0 and p.stdout.strip():
+                r = json.loads(p.stdout.strip().splitlines()[-1])
+                if r.get("verified"):
+                    return {
+                        "value": round(r["gkeys_per_s"], 5), "unit": "Gkeys/s", "cores": 64, "kind": "reference",
+                        "sample": f"reference sort() with its mandatory 64 pthreads on 2^{logn_mt} (u32<<32 key, rid=key) tuples, "
+                                  f"numa=2 arrays, fudge=2.0, median of 3 runs {r['median_s']:.2f} s, every run verified "
+                                  f"(order, key==rid, sum, xor); host has {r['logical_cpus']} logical cpus",
+                        "single_thread_core": single,
+                    }
+                note = "reference sort() produced a wrong result (it is nondeterministic, SURVEY.md section 0.9)"
+            else:
+                note = f"reference sort() exited with {p.returncode}"
+        except Exception as e:  # timeout, crash
+            note = f"reference sort() did not finish: {type(e).__name__}"
+    single["sample"] += f"; multi-thread sort() not reported: {note}"
+    return single
 
 
 def main():
@@ -205,7 +237,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0:
-        out["cpu_baseline"] = None if (args.no_cpu_baseline or N > 1) else cpu_baseline(args.cpu_logn)
+        out["cpu_baseline"] = None if (args.no_cpu_baseline or N > 1) else cpu_baseline(args.cpu_logn, args.cpu_logn_1t)
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.destroy_process_group()
