@@ -195,11 +195,6 @@ static void phase_end(msd_ctx *c)
 
 // ------------------------------------------------------------ round planning
 
-template <typename K, typename V> struct Elem {
-	static constexpr size_t key = sizeof(K);
-	static constexpr size_t val = has_val<V>::value ? 8 : 0;
-};
-
 struct RoundPlan {
 	std::vector<Parent> parents;
 	std::vector<Stripe> stripes;

@@ -295,7 +295,7 @@ def test_reference_api_sort_and_check(ctx):
     assert int(times[9]) >= int(times[0])
 
 
-@pytest.mark.parametrize("logn,kind", [(26, "uniform"), (26, "zipf"), (30, "uniform"), (30, "zipf")])
+@pytest.mark.parametrize("logn,kind", [(26, "uniform"), (26, "zipf"), (30, "uniform"), (30, "zipf"), (32, "uniform")])
 def test_full_size_properties(ctx, logn, kind):
     """BASELINE.json configs[1], [2] at full size: sorted, checksums preserved, idempotent."""
     import torch
