@@ -50,6 +50,53 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None):
     return out
 
 
+def sort_sharded_u32_sampled(engine, keys, recv, dist, world: int, group=None, sample_per_rank: int = 65536):
+    """Skew-robust variant (the reference's own scheme, src/msb_64.c:1511-1564): every rank sorts
+    its shard, contributes an equidistant sample of it, all ranks derive the same world-1 equi-depth
+    splitters with the reference's duplicate rule (:func:`splitters_equi_depth`), the sorted shard
+    is cut at the splitters (range p = keys in (delim[p-1], delim[p]]), ONE all-to-all(v) moves the
+    ranges, and each rank sorts what it received (world sorted runs).  A single key value heavier
+    than 1/world of the data cannot be split (the reference's limitation too): balance degrades,
+    the result stays correct as long as ``recv`` is large enough."""
+    import torch
+    if world == 1:
+        engine.sort_u32(keys)
+        return keys
+    n = keys.numel()
+    engine.sort_u32(keys)
+    # ---- sample: equidistant picks of the sorted shard (as unsigned values in int64)
+    m = min(sample_per_rank, n)
+    idx = (torch.arange(m, device=keys.device, dtype=torch.int64) * n) // max(m, 1)
+    mine = keys[idx].to(torch.int64) & 0xFFFFFFFF
+    cnt = torch.tensor([m], dtype=torch.int64, device=keys.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    mmax = int(max(int(c.item()) for c in cnts))
+    pad = torch.full((mmax,), -1, dtype=torch.int64, device=keys.device)
+    pad[:m] = mine
+    allp = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(allp, pad, group=group)
+    sample = torch.cat([p[: int(c.item())] for p, c in zip(allp, cnts)]).sort().values.cpu().numpy()
+    delim = splitters_equi_depth(sample, world) if len(sample) else [0] * (world - 1)
+    # ---- cut the sorted shard: keys <= delim[p] belong to ranges <= p
+    ukeys = keys.to(torch.int64) & 0xFFFFFFFF
+    d = torch.tensor(delim, dtype=torch.int64, device=keys.device)
+    cuts = torch.searchsorted(ukeys, d, right=True)
+    bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=keys.device), cuts,
+                        torch.tensor([n], dtype=torch.int64, device=keys.device)])
+    send = bounds[1:] - bounds[:-1]
+    got = torch.empty_like(send)
+    dist.all_to_all_single(got, send, group=group)
+    send_l, got_l = send.tolist(), got.tolist()
+    total = int(sum(got_l))
+    if total > recv.numel():
+        raise RuntimeError(f"receive buffer too small: {total} keys for capacity {recv.numel()}")
+    out = recv[:total]
+    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    engine.sort_u32(out)
+    return out
+
+
 def splitters_equi_depth(sorted_sample, parts: int):
     """parts-1 equi-depth delimiters from a sorted sample with the reference's duplicate
     rule (extract_delimiters, src/msb_64.c:1304-1322): if more repetitions of the picked

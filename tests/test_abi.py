@@ -60,3 +60,28 @@ def test_code_object_is_gfx950_only():
     assert b"gfx950" in data
     for other in (b"gfx90a", b"gfx942", b"sm_80"):
         assert other not in data
+
+
+def _build_c_driver(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "benchmark_msb_64")
+    lib_dir = os.path.join(ROOT, "inplacemsdradixsort_amd")
+    from inplacemsdradixsort_amd import build
+    build()
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "benchmark_msb_64.c"), "-L" + lib_dir, "-linpmsdradix_hip",
+                           "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_plain_c_caller_compiles_and_links_against_the_abi(tmp_path):
+    """A C caller of the reference library (include/msb_64.h: sort, mamalloc, check) builds unchanged."""
+    assert os.path.exists(_build_c_driver(tmp_path))
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_runs(tmp_path):
+    import subprocess
+    out = subprocess.run([_build_c_driver(tmp_path), "22", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "checksum ok" in out.stdout and "Total sort() time" in out.stdout

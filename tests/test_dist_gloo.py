@@ -40,11 +40,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, kind, q):
+def _worker(rank, world, port, n, kind, q, sampled=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from inplacemsdradixsort_amd.dist import sort_sharded_u32
+    from inplacemsdradixsort_amd.dist import sort_sharded_u32, sort_sharded_u32_sampled
     from oracle import oracle as O
     if kind == "uniform":
         k = O.gen_uniform_u32(n, first=rank * n)
@@ -52,7 +52,8 @@ def _worker(rank, world, port, n, kind, q):
         k = O.gen_zipf_u32(n, first=rank * n)
     keys = torch.from_numpy(k.view(np.int32).copy())
     recv = torch.empty(n * world, dtype=torch.int32)
-    out = sort_sharded_u32(NumpyEngine(), keys, recv, dist, world)
+    fn = sort_sharded_u32_sampled if sampled else sort_sharded_u32
+    out = fn(NumpyEngine(), keys, recv, dist, world)
     q.put((rank, out.numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -80,6 +81,29 @@ def test_sharded_sort_over_gloo(world, kind):
         if res[r].size:
             lg = world.bit_length() - 1
             assert ((res[r] >> np.uint32(32 - lg)) == r).all()
+
+
+@pytest.mark.parametrize("world,kind", [(2, "zipf"), (4, "zipf"), (4, "uniform")])
+def test_sampled_splitter_sort_over_gloo(world, kind):
+    """Skew path: equi-depth splitters with the reference's duplicate rule; ranks stay balanced on Zipf keys."""
+    n = 30000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    gen = O.gen_uniform_u32 if kind == "uniform" else O.gen_zipf_u32
+    allk = np.concatenate([gen(n, first=r * n) for r in range(world)])
+    got = np.concatenate([res[r] for r in range(world)])
+    assert (got == O.sort_u32(allk)).all()
+    sizes = [res[r].size for r in range(world)]
+    assert max(sizes) < 1.35 * n, sizes          # the radix split would put ~75 % of Zipf keys on rank 0
 
 
 def test_splitters_follow_the_reference_duplicate_rule():

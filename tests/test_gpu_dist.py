@@ -18,7 +18,14 @@ pytestmark = pytest.mark.gpu
 
 
 class GlooViaCpu:
-    """all_to_all_single for CUDA tensors over the gloo backend (copies through host memory)."""
+    """all_to_all_single / all_gather for CUDA tensors over the gloo backend (copies through host memory)."""
+
+    @staticmethod
+    def all_gather(outs, t, group=None):
+        tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        dist.all_gather(tmp, t.cpu(), group=group)
+        for o, x in zip(outs, tmp):
+            o.copy_(x)
 
     @staticmethod
     def all_to_all_single(output, input, output_split_sizes=None, input_split_sizes=None, group=None):
@@ -36,18 +43,18 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, kind, q):
+def _worker(rank, world, port, n, kind, q, sampled=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from inplacemsdradixsort_amd import MsdContext
-    from inplacemsdradixsort_amd.dist import sort_sharded_u32
+    from inplacemsdradixsort_amd.dist import sort_sharded_u32, sort_sharded_u32_sampled
     ctx = MsdContext(0)
     keys = torch.empty(n, dtype=torch.int32, device="cuda:0")
     (ctx.gen_uniform_u32 if kind == "uniform" else ctx.gen_zipf_u32)(keys, first=rank * n)
     v0, s0, x0 = ctx.check(keys)
     recv = torch.empty(n * world, dtype=torch.int32, device="cuda:0")
-    out = sort_sharded_u32(ctx, keys, recv, GlooViaCpu, world)
+    out = (sort_sharded_u32_sampled if sampled else sort_sharded_u32)(ctx, keys, recv, GlooViaCpu, world)
     v, s, x = ctx.check(out)
     lo = int(out[0].item()) & 0xFFFFFFFF if out.numel() else -1
     hi = int(out[-1].item()) & 0xFFFFFFFF if out.numel() else -1
@@ -85,3 +92,26 @@ def test_sharded_sort_real_engine(world, kind, n):
         if r[1]:
             assert (r[7] >> (32 - lg)) == r[0] and (r[8] >> (32 - lg)) == r[0] and r[7] > prev_hi
             prev_hi = r[8]
+
+
+@pytest.mark.parametrize("world,kind,n", [(2, "zipf", 1 << 21), (4, "zipf", 1 << 20)])
+def test_sampled_splitter_sort_real_engine(world, kind, n):
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n, kind, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sum(r[1] for r in res) == n * world and all(r[2] == 0 for r in res)
+    M = 1 << 64
+    assert sum(r[3] for r in res) % M == sum(r[5] for r in res) % M
+    prev_hi = -1
+    for r in res:
+        if r[1]:
+            assert r[7] > prev_hi or (r[7] == prev_hi and False)
+            prev_hi = r[8]
+    assert max(r[1] for r in res) < 1.35 * n      # balanced although 75 % of the keys share the top byte
