@@ -92,6 +92,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t chain_steps;  // cumulative (stat)
 	uint32_t ncount;       // cumulative: segments for the one-pass counting sort (<= 16 bits left)
 	uint32_t nfallback;    // counting-sort segments handed to the general LDS sort (byte counter overflow)
+	uint32_t nbig;         // cumulative: segments of any size with <= 16 bits left (multi-workgroup counting sort)
+	uint32_t pad[3];
 };
 
 // ---------------------------------------------------------------- utilities
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArr
 // children -> next round's parents / the small-segment lists / done
 __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, ChildArrays ca,
 	uint64_t small_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
-	Segment *__restrict__ small, Segment *__restrict__ small_count,
+	Segment *__restrict__ small, Segment *__restrict__ small_count, Segment *__restrict__ big, uint32_t big_cap,
 	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out)
 {
 	const Parent pa = parents[blockIdx.x];
@@ -888,9 +890,14 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 	s.count = c;
 	s.bits = pa.shift;
 	s.pad = 0;
-	if (c > small_max)
-		next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
-	else if (pa.shift <= count_bits && c >= 64) { // all remaining bits in one unstable counting pass
+	if (c > small_max) {
+		uint32_t at = 0xFFFFFFFFu;
+		if (big && pa.shift <= count_bits && c < 0xFFFF0000ull) at = atomicAdd(&ctr->nbig, 1u);
+		if (at < big_cap)
+			big[at] = s; // no further round: counted and re-generated by the multi-workgroup counting sort
+		else
+			next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
+	} else if (pa.shift <= count_bits && c >= 64) { // all remaining bits in one unstable counting pass
 		const uint32_t at = atomicAdd(&ctr->ncount, 1u);
 		if (at < small_cap) small_count[at] = s; else atomicAdd(&ctr->errors, 1u);
 	} else {
@@ -1003,6 +1010,167 @@ __global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ ke
 		}
 		__syncthreads();
 		for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = stage[i];
+		__syncthreads();
+	}
+}
+
+// ------------------------------------- counting sort for segments of any size
+
+// Keys-only segments with <= 16 open bits that do not fit LDS: every tile of a segment counts its
+// values in LDS (16-bit counters, a tile has < 65536 keys) and adds them to the segment's global
+// histogram; a scan turns counts into positions; every output tile is then re-generated from the
+// prefix array (value-parallel, long runs filled by whole waves) and stored coalesced.  One read and
+// one write of the segment replace all remaining partition rounds, whatever the key distribution.
+struct BigTile {
+	uint64_t off;  // first element of the tile, relative to the segment
+	uint32_t len;  // elements (<= kBigTile)
+	uint32_t seg;  // index into the big-segment list
+};
+constexpr uint32_t kBigTile = 32768;       // keys per tile: 128 KiB of LDS staging for u32
+constexpr uint32_t kBigRun = 32;           // longer runs are filled cooperatively
+constexpr uint32_t kBigHeavyCap = 1024;
+constexpr size_t kBigHistLds = 32768 * 4;  // 2^16 16-bit counters
+constexpr size_t kBigWriteLds = (size_t)kBigTile * 4 + kBigHeavyCap * 12 + 64;
+
+template <typename K>
+__global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict__ keys,
+	const Segment *__restrict__ segs, const BigTile *__restrict__ tiles, uint32_t *__restrict__ ghist)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem); // two 16-bit counters per word
+	const BigTile tl = tiles[blockIdx.x];
+	const Segment sg = segs[tl.seg];
+	const uint32_t nv = 1u << sg.bits, mask = nv - 1u, nwords = nv >= 2 ? nv / 2 : 1, tid = threadIdx.x;
+	for (uint32_t j = tid; j < nwords; j += 1024) cw[j] = 0;
+	__syncthreads();
+	const K *src = keys + sg.start + tl.off;
+	for (uint32_t i0 = 0; i0 < tl.len; i0 += 4 * 1024) {
+		K k4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t idx = i0 + u * 1024 + tid;
+			k4[u] = idx < tl.len ? src[idx] : (K)0;
+		}
+#pragma unroll
+		for (int u = 0; u < 4; ++u) {
+			const uint32_t idx = i0 + u * 1024 + tid;
+			if (idx < tl.len) {
+				const uint32_t v = (uint32_t)k4[u] & mask;
+				atomicAdd(&cw[v >> 1], 1u << (16u * (v & 1u)));
+			}
+		}
+	}
+	__syncthreads();
+	uint32_t *gh = ghist + (size_t)tl.seg * 65536;
+	for (uint32_t j = tid; j < nwords; j += 1024) {
+		const uint32_t w = cw[j];
+		if (w & 0xFFFFu) atomicAdd(&gh[2 * j], w & 0xFFFFu);
+		if (w >> 16) atomicAdd(&gh[2 * j + 1], w >> 16);
+	}
+}
+
+// counts -> exclusive prefix (in place); also records the segment's common key prefix
+template <typename K>
+__global__ __launch_bounds__(1024) void bigcount_scan_kernel(const K *__restrict__ keys,
+	const Segment *__restrict__ segs, uint32_t *__restrict__ ghist, K *__restrict__ seg_hi, Counters *__restrict__ ctr)
+{
+	__shared__ uint32_t wtot[16];
+	const Segment sg = segs[blockIdx.x];
+	const uint32_t nv = 1u << sg.bits, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t per = nv >= 1024 ? nv / 1024 : 1;
+	uint32_t *gh = ghist + (size_t)blockIdx.x * 65536;
+	const uint32_t v0 = tid * per;
+	uint32_t tot = 0;
+	if (v0 < nv)
+		for (uint32_t j = 0; j < per; ++j) tot += gh[v0 + j];
+	const uint32_t inc = wave_incl_scan(tot);
+	if (lane == 63) wtot[w] = inc;
+	__syncthreads();
+	uint32_t run = inc - tot;
+	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
+	if (v0 < nv)
+		for (uint32_t j = 0; j < per; ++j) {
+			const uint32_t c = gh[v0 + j];
+			gh[v0 + j] = run;
+			run += c;
+		}
+	if (tid == 1023) {
+		if (run != (uint32_t)sg.count) atomicAdd(&ctr->errors, 1u); // every key was counted exactly once
+		const K mask = (K)nv - 1;
+		seg_hi[blockIdx.x] = keys[sg.start] & ~mask;
+	}
+}
+
+template <typename K>
+__global__ __launch_bounds__(1024) void bigcount_write_kernel(K *__restrict__ keys,
+	const Segment *__restrict__ segs, const BigTile *__restrict__ tiles, const uint32_t *__restrict__ ghist,
+	const K *__restrict__ seg_hi)
+{
+	constexpr uint32_t TILE = kBigTile * 4 / sizeof(K); // elements staged per workgroup
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	K *stage = reinterpret_cast<K *>(smem);
+	uint32_t *heavy = reinterpret_cast<uint32_t *>(smem + (size_t)kBigTile * 4); // (value, begin, count) triples
+	uint32_t *misc = heavy + kBigHeavyCap * 3;                                    // [0] v_lo [1] v_hi [2] nheavy
+	const BigTile tl = tiles[blockIdx.x];
+	const Segment sg = segs[tl.seg];
+	const uint32_t nv = 1u << sg.bits, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t *P = ghist + (size_t)tl.seg * 65536; // exclusive prefix per value
+	const K hi = seg_hi[tl.seg];
+	const uint32_t total = (uint32_t)sg.count;
+	for (uint32_t sub = 0; sub < tl.len; sub += TILE) { // (u64 keys stage half a tile at a time)
+		const uint32_t off = (uint32_t)tl.off + sub;
+		const uint32_t len = tl.len - sub < TILE ? tl.len - sub : TILE;
+		if (w == 0) {
+			// v_lo: last value whose run starts at or before `off`; v_hi: last value whose run starts
+			// before off+len.  64-ary search: every lane probes one position per step (3 steps for 2^16).
+			auto last_le = [&](uint32_t target, uint32_t lo0) {
+				uint32_t lo = lo0, range = nv - lo0; // invariant: P[lo] <= target (P[0] = 0), answer in [lo, lo+range)
+				while (range > 1) {
+					const uint32_t step = (range + 63) / 64;
+					const uint32_t idx = lo + lane * step;
+					const bool ok = lane * step < range && P[idx] <= target;
+					const uint64_t m = __ballot(ok);
+					const uint32_t top = 63u - (uint32_t)__builtin_clzll(m | 1ull);
+					lo += top * step;
+					range = range - top * step < step ? range - top * step : step;
+				}
+				return lo;
+			};
+			const uint32_t a = last_le(off, 0);
+			const uint32_t b2 = last_le(off + len - 1, a);
+			if (lane == 0) {
+				misc[0] = a;
+				misc[1] = b2;
+				misc[2] = 0;
+			}
+		}
+		__syncthreads();
+		const uint32_t v_lo = misc[0], v_hi = misc[1];
+		for (uint32_t v = v_lo + tid; v <= v_hi; v += 1024) {
+			const uint32_t pb = P[v], pe = v + 1 < nv ? P[v + 1] : total;
+			const uint32_t b = pb > off ? pb : off, e = pe < off + len ? pe : off + len;
+			if (e > b) {
+				const K kv = hi | (K)v;
+				if (e - b <= kBigRun) {
+					for (uint32_t i = b; i < e; ++i) stage[i - off] = kv;
+				} else {
+					const uint32_t at = atomicAdd(&misc[2], 1u);
+					heavy[3 * at] = v;
+					heavy[3 * at + 1] = b - off;
+					heavy[3 * at + 2] = e - b;
+				}
+			}
+		}
+		__syncthreads();
+		const uint32_t nheavy = misc[2];
+		for (uint32_t hidx = w; hidx < nheavy; hidx += 16) {
+			const K kv = hi | (K)heavy[3 * hidx];
+			const uint32_t s0 = heavy[3 * hidx + 1], c = heavy[3 * hidx + 2];
+			for (uint32_t i = lane; i < c; i += 64) stage[s0 + i] = kv;
+		}
+		__syncthreads();
+		K *dst = keys + sg.start + off;
+		for (uint32_t i = tid; i < len; i += 1024) dst[i] = stage[i];
 		__syncthreads();
 	}
 }

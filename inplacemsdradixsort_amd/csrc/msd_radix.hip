@@ -365,6 +365,7 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 	Bump b(nullptr);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
 	b.take<Counters>(2); // counters + scratch for the varying-bit reduction
+	b.take<Segment>(n / ((uint64_t)Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT) + 16); // big counting-sort segments
 	return b.off + 4096;
 }
 
@@ -431,6 +432,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	Bump kb(c->keep);
 	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
 	Counters *ctr = kb.take<Counters>(2);
+	const uint32_t big_cap = (uint32_t)std::min<uint64_t>(n / small_max + 16, 0x7FFFFFFFu);
+	Segment *big = kb.take<Segment>(big_cap);
 	Segment *small = c->lists, *small_count = c->lists + 2 * c->lists_cap;
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 	// keys without payload whose last <= 16 bits are open are finished by the counting sort
@@ -476,7 +479,16 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		phase_mark(c, "bit skip");
 	}
 
-	uint32_t nsmall_host = 0, ncount_host = 0;
+	uint32_t nsmall_host = 0, ncount_host = 0, nbig_host = 0;
+	if constexpr (!HV) { // <= 16 open bits from the start (small key range): no partition round at all
+		if (!single_pass && !cur.empty() && n > small_max && cur[0].bits <= count_bits && n < 0xFFFF0000ull) {
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			memcpy(c->pinned, &cur[0], sizeof(Segment));
+			HIPCHK(c, hipMemcpyAsync(big, c->pinned, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+			nbig_host = 1;
+			cur.clear();
+		}
+	}
 	if (!single_pass && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(c->pinned, &cur[0], sizeof(Segment));
@@ -562,7 +574,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		hipLaunchKernelGGL((excess_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, (const K *)rb.xkeys, rb.xvals, keys, vals);
 		hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, rb.parents, rb.ca,
 				   single_pass ? ~0ull : small_max, small_cap, single_pass ? 0u : count_bits,
-				   rb.next_parents, small, small_count, ctr,
+				   rb.next_parents, small, small_count, (HV || single_pass) ? (Segment *)nullptr : big, big_cap, ctr,
 				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "C cleanup");
@@ -575,6 +587,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations", round, hc.errors);
 		nsmall_host = hc.nsmall;
 		ncount_host = hc.ncount;
+		nbig_host = hc.nbig;
 		add_stat(c, "rounds", 1);
 		add_stat(c, "parents", np);
 		add_stat(c, "stripes", ns);
@@ -596,6 +609,54 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		phase_mark(c, "readback");
 		++round;
 	}
+
+	// ---- keys-only segments of any size with <= 16 open bits: multi-workgroup counting sort
+	if constexpr (!HV) {
+		if (nbig_host && !single_pass) {
+			int rc = pinned_reserve(c, (size_t)nbig_host * sizeof(Segment));
+			if (rc) return rc;
+			HIPCHK(c, hipMemcpyAsync(c->pinned, big, (size_t)nbig_host * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			std::vector<Segment> bs((Segment *)c->pinned, (Segment *)c->pinned + nbig_host);
+			const uint32_t batch_max = 4096; // 256 KiB of histogram per segment: 1 GiB per batch
+			for (uint32_t b0 = 0; b0 < nbig_host; b0 += batch_max) {
+				const uint32_t nb = std::min(batch_max, nbig_host - b0);
+				std::vector<BigTile> tiles;
+				for (uint32_t i = 0; i < nb; ++i)
+					for (uint64_t off = 0; off < bs[b0 + i].count; off += kBigTile)
+						tiles.push_back({ off, (uint32_t)std::min<uint64_t>(kBigTile, bs[b0 + i].count - off), i });
+				Bump sz(nullptr);
+				sz.take<uint32_t>((size_t)nb * 65536);
+				sz.take<K>(nb);
+				sz.take<BigTile>(tiles.size());
+				rc = slab_reserve(c, sz.off + 4096); // the round slab is dead by now
+				if (!rc) rc = pinned_reserve(c, tiles.size() * sizeof(BigTile));
+				if (rc) return rc;
+				Bump bb(c->slab);
+				uint32_t *ghist = bb.take<uint32_t>((size_t)nb * 65536);
+				K *seg_hi = bb.take<K>(nb);
+				BigTile *dtiles = bb.take<BigTile>(tiles.size());
+				HIPCHK(c, hipStreamSynchronize(c->stream));
+				memcpy(c->pinned, tiles.data(), tiles.size() * sizeof(BigTile));
+				HIPCHK(c, hipMemcpyAsync(dtiles, c->pinned, tiles.size() * sizeof(BigTile), hipMemcpyHostToDevice, c->stream));
+				HIPCHK(c, hipMemsetAsync(ghist, 0, (size_t)nb * 65536 * sizeof(uint32_t), c->stream));
+				hipLaunchKernelGGL((bigcount_hist_kernel<K>), dim3((unsigned)tiles.size()), dim3(1024), kBigHistLds, c->stream,
+						   (const K *)keys, big + b0, dtiles, ghist);
+				hipLaunchKernelGGL((bigcount_scan_kernel<K>), dim3(nb), dim3(1024), 0, c->stream,
+						   (const K *)keys, big + b0, ghist, seg_hi, ctr);
+				hipLaunchKernelGGL((bigcount_write_kernel<K>), dim3((unsigned)tiles.size()), dim3(1024), kBigWriteLds, c->stream,
+						   keys, big + b0, dtiles, (const uint32_t *)ghist, (const K *)seg_hi);
+				HIPCHK(c, hipGetLastError());
+			}
+			phase_mark(c, "big count sort");
+			Counters hc2;
+			HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			memcpy(&hc2, c->pinned, sizeof hc2);
+			if (hc2.errors) return fail(c, MSD_EINTERNAL, "counting sort: %u histogram totals disagree with segment sizes", hc2.errors);
+		}
+	}
+	set_stat(c, "big_count_segments", nbig_host);
 
 	// ---- segments that fit LDS are finished there
 	if (!single_pass) {
@@ -633,9 +694,14 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
-	if constexpr (!has_val<V>::value)
+	if constexpr (!has_val<V>::value) {
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_sort_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&bigcount_hist_kernel<K>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigHistLds));
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&bigcount_write_kernel<K>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigWriteLds));
+	}
 	return MSD_OK;
 }
 

@@ -73,6 +73,32 @@ def test_sort_u32_mid_sizes_equal_oracle(ctx, n, kind):
     assert (host(t) == O.sort_u32(k)).all()
 
 
+@pytest.mark.parametrize("kind", ["lowbits12", "range16", "heavy", "zipf", "twovalues"])
+@pytest.mark.parametrize("n", [30000, (1 << 20) + 7, 1 << 23])
+def test_big_counting_sort_paths(ctx, n, kind):
+    """Segments with <= 16 open bits that exceed the LDS leaf: multi-workgroup counting sort
+    (small key ranges from the start, and the heavy buckets of skewed inputs after two rounds)."""
+    rng = np.random.default_rng(n)
+    if kind == "lowbits12":
+        k = rng.integers(0, 1 << 12, n, dtype=np.uint32)
+    elif kind == "range16":
+        k = rng.integers(0, 1 << 16, n, dtype=np.uint32) | np.uint32(0x12340000)
+    elif kind == "heavy":      # one value holds half of the keys, the rest is spread over 16 bits
+        k = rng.integers(0, 1 << 16, n, dtype=np.uint32)
+        k[rng.random(n) < 0.5] = 777
+    elif kind == "zipf":
+        k = O.gen_zipf_u32(n, seed=n)
+    else:
+        k = np.where(rng.random(n) < 0.3, np.uint32(5), np.uint32(0xFFFF0005)).astype(np.uint32)
+    t = dev(k)
+    ctx.sort_u32(t)
+    assert (host(t) == np.sort(k)).all()
+    k64 = k.astype(np.uint64) | (np.uint64(0xABCD) << np.uint64(48))
+    t = dev(k64)
+    ctx.sort_u64(t)
+    assert (host(t) == np.sort(k64)).all()
+
+
 def test_sort_u32_config_c1(ctx):
     """BASELINE.json configs[0]: 2^20 uniform u32; digest produced by the reference."""
     import hashlib
