@@ -294,7 +294,25 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 
 		// ---- rank every key inside its bucket for this tile (LDS fetch-add)
 		uint32_t dr[KPT]; // digit | rank<<8
-		if (full) {
+		if (full && tmp[8 + (par ^ 1)]) {
+			// the previous tile was skewed: lanes that share lane 0's digit take ONE fetch-add together
+			// (a same-address LDS atomic serialises per lane)
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) {
+				const uint32_t d = digit_of(kc[i], shift, mask);
+				const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+				const uint64_t same = __ballot(d == d0);
+				uint32_t r;
+				if (__popcll(same) >= 8) {
+					uint32_t base = 0;
+					if (lane_id() == 0) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(same));
+					base = __builtin_amdgcn_readfirstlane(base);
+					r = d == d0 ? base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)) : atomicAdd(&cnt[d], 1u);
+				} else
+					r = atomicAdd(&cnt[d], 1u);
+				dr[i] = d | (r << 8);
+			}
+		} else if (full) {
 #pragma unroll
 			for (int i = 0; i < KPT; ++i) {
 				const uint32_t d = digit_of(kc[i], shift, mask);
@@ -315,7 +333,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 
 		// ---- per bucket: blocks completed by this tile claim consecutive output slots
 		if (tid < kP) {
-			const uint32_t L_r = fill_r + cnt[tid];
+			const uint32_t ct = cnt[tid];
+			if (ct > (uint32_t)T / 16) tmp[8 + par] = 1; // skewed tile: the next one aggregates equal digits per wave
+			const uint32_t L_r = fill_r + ct;
 			cnt[tid] = 0;
 			const uint32_t nb_r = L_r / B;
 			uint32_t bbase = 0;
@@ -331,6 +351,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 		if (tid == 0) { // the other parity's counters were last read before B1
 			tmp[par ^ 1] = 0;
 			tmp[2 + (par ^ 1)] = 0;
+			tmp[8 + (par ^ 1)] = 0;
 		}
 		__syncthreads(); // B2
 		const uint32_t nbtot = tmp[par], njobs = tmp[2 + par];
@@ -1029,47 +1050,53 @@ struct BigTile {
 constexpr uint32_t kBigTile = 32768;       // keys per tile: 128 KiB of LDS staging for u32
 constexpr uint32_t kBigRun = 32;           // longer runs are filled cooperatively
 constexpr uint32_t kBigHeavyCap = 1024;
-constexpr size_t kBigHistLds = 32768 * 4;  // 2^16 16-bit counters
+constexpr size_t kBigHistLds = 32768 * 4;  // 2^15 32-bit counters (half of the value range per pass)
+constexpr uint32_t kBigChunk = 1u << 22;   // keys per histogram workgroup
 constexpr size_t kBigWriteLds = (size_t)kBigTile * 4 + kBigHeavyCap * 12 + 64;
 
 template <typename K>
 __global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict__ keys,
-	const Segment *__restrict__ segs, const BigTile *__restrict__ tiles, uint32_t *__restrict__ ghist)
+	const Segment *__restrict__ segs, const BigTile *__restrict__ chunks, uint32_t *__restrict__ ghist)
 {
+	// 32-bit LDS counters for half of the 2^16 value range: a chunk of millions of keys is read once
+	// per half (twice in all), so the merge into the segment's global histogram -- one coalesced
+	// atomic add per counter -- is negligible per key.
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint32_t *cw = reinterpret_cast<uint32_t *>(smem); // two 16-bit counters per word
-	const BigTile tl = tiles[blockIdx.x];
-	const Segment sg = segs[tl.seg];
-	const uint32_t nv = 1u << sg.bits, mask = nv - 1u, nwords = nv >= 2 ? nv / 2 : 1, tid = threadIdx.x;
-	for (uint32_t j = tid; j < nwords; j += 1024) cw[j] = 0;
-	__syncthreads();
-	const K *src = keys + sg.start + tl.off;
-	for (uint32_t i0 = 0; i0 < tl.len; i0 += 4 * 1024) {
-		K k4[4];
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);
+	const BigTile ch = chunks[blockIdx.x];
+	const Segment sg = segs[ch.seg];
+	const uint32_t nv = 1u << sg.bits, mask = nv - 1u, tid = threadIdx.x;
+	const uint32_t half = nv > 32768u ? 32768u : nv;
+	const K *src = keys + sg.start + ch.off;
+	uint32_t *gh = ghist + (size_t)ch.seg * 65536;
+	for (uint32_t base = 0; base < nv; base += half) {
+		for (uint32_t j = tid; j < half; j += 1024) cw[j] = 0;
+		__syncthreads();
+		for (uint32_t i0 = 0; i0 < ch.len; i0 += 4 * 1024) {
+			K k4[4];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t idx = i0 + u * 1024 + tid;
-			k4[u] = idx < tl.len ? src[idx] : (K)0;
-		}
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t idx = i0 + u * 1024 + tid;
+				k4[u] = idx < ch.len ? src[idx] : (K)0;
+			}
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t idx = i0 + u * 1024 + tid;
-			if (idx < tl.len) {
-				const uint32_t v = (uint32_t)k4[u] & mask;
-				atomicAdd(&cw[v >> 1], 1u << (16u * (v & 1u)));
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t idx = i0 + u * 1024 + tid;
+				const uint32_t v = ((uint32_t)k4[u] & mask) - base;
+				if (idx < ch.len && v < half) atomicAdd(&cw[v], 1u);
 			}
 		}
-	}
-	__syncthreads();
-	uint32_t *gh = ghist + (size_t)tl.seg * 65536;
-	for (uint32_t j = tid; j < nwords; j += 1024) {
-		const uint32_t w = cw[j];
-		if (w & 0xFFFFu) atomicAdd(&gh[2 * j], w & 0xFFFFu);
-		if (w >> 16) atomicAdd(&gh[2 * j + 1], w >> 16);
+		__syncthreads();
+		for (uint32_t j = tid; j < half; j += 1024) {
+			const uint32_t c = cw[j];
+			if (c) atomicAdd(&gh[base + j], c);
+		}
+		__syncthreads();
 	}
 }
 
-// counts -> exclusive prefix (in place); also records the segment's common key prefix
+// counts -> exclusive prefix (in place); also records the segment's common key prefix.
+// Wave w owns the contiguous values [w*nv/16, (w+1)*nv/16) and walks them 64 at a time (coalesced).
 template <typename K>
 __global__ __launch_bounds__(1024) void bigcount_scan_kernel(const K *__restrict__ keys,
 	const Segment *__restrict__ segs, uint32_t *__restrict__ ghist, K *__restrict__ seg_hi, Counters *__restrict__ ctr)
@@ -1077,24 +1104,25 @@ __global__ __launch_bounds__(1024) void bigcount_scan_kernel(const K *__restrict
 	__shared__ uint32_t wtot[16];
 	const Segment sg = segs[blockIdx.x];
 	const uint32_t nv = 1u << sg.bits, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const uint32_t per = nv >= 1024 ? nv / 1024 : 1;
 	uint32_t *gh = ghist + (size_t)blockIdx.x * 65536;
-	const uint32_t v0 = tid * per;
+	const uint32_t per = (nv + 15) / 16;                  // values per wave
+	const uint32_t v0 = w * per, v1 = v0 + per < nv ? v0 + per : nv;
 	uint32_t tot = 0;
-	if (v0 < nv)
-		for (uint32_t j = 0; j < per; ++j) tot += gh[v0 + j];
-	const uint32_t inc = wave_incl_scan(tot);
-	if (lane == 63) wtot[w] = inc;
+	for (uint32_t v = v0 + lane; v < v1; v += 64) tot += gh[v];
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+	if (lane == 0) wtot[w] = tot;
 	__syncthreads();
-	uint32_t run = inc - tot;
+	uint32_t run = 0;
 	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
-	if (v0 < nv)
-		for (uint32_t j = 0; j < per; ++j) {
-			const uint32_t c = gh[v0 + j];
-			gh[v0 + j] = run;
-			run += c;
-		}
-	if (tid == 1023) {
+	for (uint32_t vb = v0; vb < v1; vb += 64) {
+		const uint32_t v = vb + lane;
+		const uint32_t c = v < v1 ? gh[v] : 0u;
+		const uint32_t inc = wave_incl_scan(c);
+		if (v < v1) gh[v] = run + inc - c;
+		run += __shfl(inc, 63);
+	}
+	if (w == 15 && lane == 0) {
 		if (run != (uint32_t)sg.count) atomicAdd(&ctr->errors, 1u); // every key was counted exactly once
 		const K mask = (K)nv - 1;
 		seg_hi[blockIdx.x] = keys[sg.start] & ~mask;

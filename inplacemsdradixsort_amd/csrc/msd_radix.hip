@@ -621,7 +621,11 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			const uint32_t batch_max = 4096; // 256 KiB of histogram per segment: 1 GiB per batch
 			for (uint32_t b0 = 0; b0 < nbig_host; b0 += batch_max) {
 				const uint32_t nb = std::min(batch_max, nbig_host - b0);
-				std::vector<BigTile> tiles;
+				std::vector<BigTile> tiles; // first the histogram chunks, then the output tiles
+				for (uint32_t i = 0; i < nb; ++i)
+					for (uint64_t off = 0; off < bs[b0 + i].count; off += kBigChunk)
+						tiles.push_back({ off, (uint32_t)std::min<uint64_t>(kBigChunk, bs[b0 + i].count - off), i });
+				const size_t nchunks = tiles.size();
 				for (uint32_t i = 0; i < nb; ++i)
 					for (uint64_t off = 0; off < bs[b0 + i].count; off += kBigTile)
 						tiles.push_back({ off, (uint32_t)std::min<uint64_t>(kBigTile, bs[b0 + i].count - off), i });
@@ -635,16 +639,17 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				Bump bb(c->slab);
 				uint32_t *ghist = bb.take<uint32_t>((size_t)nb * 65536);
 				K *seg_hi = bb.take<K>(nb);
-				BigTile *dtiles = bb.take<BigTile>(tiles.size());
+				BigTile *dchunks = bb.take<BigTile>(tiles.size());
+				BigTile *dtiles = dchunks + nchunks;
 				HIPCHK(c, hipStreamSynchronize(c->stream));
 				memcpy(c->pinned, tiles.data(), tiles.size() * sizeof(BigTile));
-				HIPCHK(c, hipMemcpyAsync(dtiles, c->pinned, tiles.size() * sizeof(BigTile), hipMemcpyHostToDevice, c->stream));
+				HIPCHK(c, hipMemcpyAsync(dchunks, c->pinned, tiles.size() * sizeof(BigTile), hipMemcpyHostToDevice, c->stream));
 				HIPCHK(c, hipMemsetAsync(ghist, 0, (size_t)nb * 65536 * sizeof(uint32_t), c->stream));
-				hipLaunchKernelGGL((bigcount_hist_kernel<K>), dim3((unsigned)tiles.size()), dim3(1024), kBigHistLds, c->stream,
-						   (const K *)keys, big + b0, dtiles, ghist);
+				hipLaunchKernelGGL((bigcount_hist_kernel<K>), dim3((unsigned)nchunks), dim3(1024), kBigHistLds, c->stream,
+						   (const K *)keys, big + b0, dchunks, ghist);
 				hipLaunchKernelGGL((bigcount_scan_kernel<K>), dim3(nb), dim3(1024), 0, c->stream,
 						   (const K *)keys, big + b0, ghist, seg_hi, ctr);
-				hipLaunchKernelGGL((bigcount_write_kernel<K>), dim3((unsigned)tiles.size()), dim3(1024), kBigWriteLds, c->stream,
+				hipLaunchKernelGGL((bigcount_write_kernel<K>), dim3((unsigned)(tiles.size() - nchunks)), dim3(1024), kBigWriteLds, c->stream,
 						   keys, big + b0, dtiles, (const uint32_t *)ghist, (const K *)seg_hi);
 				HIPCHK(c, hipGetLastError());
 			}
