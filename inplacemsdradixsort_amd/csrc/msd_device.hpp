@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArr
 
 // children -> next round's parents / the small-segment lists / done
 __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, ChildArrays ca,
-	uint64_t small_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
+	uint64_t small_max, uint64_t med_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
 	Segment *__restrict__ small, Segment *__restrict__ small_count, Segment *__restrict__ big, uint32_t big_cap,
 	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out)
 {
@@ -911,16 +911,17 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 	s.count = c;
 	s.bits = pa.shift;
 	s.pad = 0;
-	if (c > small_max) {
+	const bool countable = pa.shift <= count_bits; // all open bits fit one counting pass
+	if (countable && c >= 64 && c <= med_max) {     // one workgroup: LDS byte counters
+		const uint32_t at = atomicAdd(&ctr->ncount, 1u);
+		if (at < small_cap) small_count[at] = s; else atomicAdd(&ctr->errors, 1u);
+	} else if (c > small_max) {
 		uint32_t at = 0xFFFFFFFFu;
-		if (big && pa.shift <= count_bits && c < 0xFFFF0000ull) at = atomicAdd(&ctr->nbig, 1u);
+		if (big && countable && c < 0xFFFF0000ull) at = atomicAdd(&ctr->nbig, 1u);
 		if (at < big_cap)
 			big[at] = s; // no further round: counted and re-generated by the multi-workgroup counting sort
 		else
 			next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
-	} else if (pa.shift <= count_bits && c >= 64) { // all remaining bits in one unstable counting pass
-		const uint32_t at = atomicAdd(&ctr->ncount, 1u);
-		if (at < small_cap) small_count[at] = s; else atomicAdd(&ctr->errors, 1u);
 	} else {
 		const uint32_t at = atomicAdd(&ctr->nsmall, 1u);
 		if (at < small_cap) small[at] = s; else atomicAdd(&ctr->errors, 1u);
@@ -937,6 +938,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 // workgroup then leaves the segment untouched and queues it for the general LDS sort.
 constexpr int kCountTh = 1024;
 constexpr int kCountMaxBits = 16;
+constexpr uint64_t kCountMedMax = 1ull << 17; // largest segment one workgroup counts by itself
 // counter word i lives at i + i/32: a thread's 16 consecutive words and its neighbours' then
 // fall on different LDS banks (unpadded, the stride-16 walk is a 32-way bank conflict)
 constexpr size_t kCountCwBytes = (((size_t)1 << kCountMaxBits) / 4 + ((size_t)1 << kCountMaxBits) / 128 + 4) * 4;
@@ -947,7 +949,7 @@ __device__ __forceinline__ uint32_t cw_at(uint32_t i) { return i + (i >> 5); }
 template <typename K>
 __global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ keys,
 	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ fallback, uint32_t fallback_base,
-	Counters *__restrict__ ctr)
+	uint32_t lds_cap, Segment *__restrict__ big, uint32_t big_cap, Counters *__restrict__ ctr)
 {
 	constexpr uint32_t WS = kCountStageBytes / sizeof(K); // keys per output window
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -986,10 +988,15 @@ __global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ ke
 	}
 	if (ovf) *flag = 1;
 	__syncthreads();
-	if (*flag) { // some value occurs > 255 times: hand the untouched segment to the general sort
+	if (*flag) { // some value occurs > 255 times: hand the untouched segment on
 		if (tid == 0) {
-			const uint32_t at = atomicAdd(&ctr->nfallback, 1u);
-			fallback[fallback_base + at] = sg;
+			if (n <= lds_cap) { // ... to the general LDS sort
+				const uint32_t at = atomicAdd(&ctr->nfallback, 1u);
+				fallback[fallback_base + at] = sg;
+			} else {            // ... to the multi-workgroup counting sort (32-bit counters)
+				const uint32_t at = big ? atomicAdd(&ctr->nbig, 1u) : 0xFFFFFFFFu;
+				if (at < big_cap) big[at] = sg; else atomicAdd(&ctr->errors, 1u);
+			}
 		}
 		return;
 	}

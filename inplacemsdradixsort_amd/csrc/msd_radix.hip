@@ -573,7 +573,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				   rb.lo_off, rb.lo_dst, rb.ca, (const K *)rb.lo_keys, rb.lo_vals, keys, vals);
 		hipLaunchKernelGGL((excess_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, (const K *)rb.xkeys, rb.xvals, keys, vals);
 		hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, rb.parents, rb.ca,
-				   single_pass ? ~0ull : small_max, small_cap, single_pass ? 0u : count_bits,
+				   single_pass ? ~0ull : small_max, (HV || single_pass) ? small_max : std::max<uint64_t>(small_max, kCountMedMax),
+				   small_cap, single_pass ? 0u : count_bits,
 				   rb.next_parents, small, small_count, (HV || single_pass) ? (Segment *)nullptr : big, big_cap, ctr,
 				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr);
 		HIPCHK(c, hipGetLastError());
@@ -610,6 +611,23 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		++round;
 	}
 
+	// ---- leaves, stage 1: one unstable counting pass over all remaining bits (one workgroup per segment)
+	constexpr size_t sort_lds = SortLds<K, V>::bytes;
+	if constexpr (!HV) {
+		if (ncount_host && !single_pass) {
+			hipLaunchKernelGGL((count_sort_kernel<K>), dim3(ncount_host), dim3(kCountTh), kCountLds, c->stream,
+					   keys, small_count, ncount_host, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
+			HIPCHK(c, hipGetLastError());
+			phase_mark(c, "count sort");
+			// byte-counter overflows of segments above the LDS-sort capacity joined the big list
+			Counters hc3;
+			HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			memcpy(&hc3, c->pinned, sizeof hc3);
+			if (hc3.errors) return fail(c, MSD_EINTERNAL, "counting leaf: %u segments could not be queued", hc3.errors);
+			nbig_host = hc3.nbig;
+		}
+	}
 	// ---- keys-only segments of any size with <= 16 open bits: multi-workgroup counting sort
 	if constexpr (!HV) {
 		if (nbig_host && !single_pass) {
@@ -663,17 +681,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 	set_stat(c, "big_count_segments", nbig_host);
 
-	// ---- segments that fit LDS are finished there
+	// ---- leaves, stage 2: the general LDS sort (payloads, > 16 open bits, counting-sort overflows)
 	if (!single_pass) {
-		constexpr size_t sort_lds = SortLds<K, V>::bytes;
-		if constexpr (!HV) {
-			if (ncount_host) { // one unstable counting pass over all remaining bits
-				hipLaunchKernelGGL((count_sort_kernel<K>), dim3(ncount_host), dim3(kCountTh), kCountLds, c->stream,
-						   keys, small_count, ncount_host, small, nsmall_host, ctr);
-				HIPCHK(c, hipGetLastError());
-				phase_mark(c, "count sort");
-			}
-		}
 		if (nsmall_host) {
 			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), sort_lds, c->stream,
 					   keys, vals, small, nsmall_host, (const uint32_t *)nullptr);
