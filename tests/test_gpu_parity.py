@@ -99,6 +99,23 @@ def test_big_counting_sort_paths(ctx, n, kind):
     assert (host(t) == np.sort(k64)).all()
 
 
+def test_counting_leaf_overflow_escalates_to_multi_workgroup_sort(ctx):
+    """A medium segment (above the LDS-sort capacity) whose hot value overflows the 8-bit LDS
+    counters must be finished by the multi-workgroup counting sort."""
+    rng = np.random.default_rng(42)
+    n = 1 << 22
+    k = rng.integers(0, 1 << 21, n, dtype=np.uint32)
+    hot = rng.random(n) < 0.02                       # one child of the first round gets ~100 K keys ...
+    k[hot] = (np.uint32(0x55) << np.uint32(13)) | rng.integers(0, 1 << 13, int(hot.sum()), dtype=np.uint32)
+    hotter = hot & (rng.random(n) < 0.3)             # ... a quarter of them one single value
+    k[hotter] = (np.uint32(0x55) << np.uint32(13)) | np.uint32(77)
+    t = dev(k)
+    ctx.sort_u32(t)
+    st = ctx.stats()
+    assert (host(t) == np.sort(k)).all()
+    assert st.get("big_count_segments", 0) >= 1 and st.get("count_segments", 0) >= 1, st
+
+
 def test_sort_u32_config_c1(ctx):
     """BASELINE.json configs[0]: 2^20 uniform u32; digest produced by the reference."""
     import hashlib
