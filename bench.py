@@ -220,6 +220,20 @@ def main():
                         "algorithmic_bytes_per_launch": int(algo),
                         "phases_us": {k: round(v, 1) for k, v in ph.items()}}
 
+    # ---- achievable copy rate on this device, same run (second denominator)
+    copy_gbps = None
+    if N == 1:
+        a, b = bufs[0], bufs[1] if len(bufs) > 1 else torch.empty_like(bufs[0])
+        b.copy_(a)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
     total_keys = N * n * K
     value = total_keys / dt / 1e9
     whole = N * n * 4 * BYTES_PER_KEY_PASS / (dt / K) / 1e9 / N  # per-GPU algorithmic GB/s (48 B/key)
@@ -233,7 +247,9 @@ def main():
                    "keys_per_gpu": n, "distribution": args.dist, "verified": bool(verified),
                    "workspace_bytes": ctx.workspace_bytes},
         "whole_sort": {"algorithmic_GBps_per_gpu": round(whole, 1), "frac_of_peak": round(whole / HBM_PEAK_GBS, 4),
-                       "bytes_per_key": 4 * BYTES_PER_KEY_PASS},
+                       "bytes_per_key": 4 * BYTES_PER_KEY_PASS,
+                       "device_copy_GBps_same_run": None if copy_gbps is None else round(copy_gbps, 1),
+                       "frac_of_device_copy": None if copy_gbps is None else round(whole / copy_gbps, 4)},
         "roofline": roofline,
     }
     if rank == 0:
