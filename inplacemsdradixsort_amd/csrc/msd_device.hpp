@@ -1042,6 +1042,95 @@ __global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ ke
 	}
 }
 
+// --------------------------------------- one-pass counting leaf with payload
+
+// (key, rid) segments that fit the LDS exchange buffers and have <= 14 open bits: one unstable
+// counting pass over all open bits.  16-bit counters (a segment has < 65536 tuples, so they cannot
+// overflow) are bumped by LDS fetch-adds whose return value is the tuple's rank among equal keys;
+// an in-place scan turns counts into positions; tuples are scattered into LDS and stored coalesced.
+constexpr int kPairCountBits = 14;
+template <typename K, typename V> struct PairCountLds {
+	static constexpr int CAP = Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT;
+	static constexpr size_t bytes = (size_t)CAP * (sizeof(K) + 8) + ((size_t)1 << kPairCountBits) * 2 + 128;
+};
+
+template <typename K, typename V>
+__global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void pair_count_sort_kernel(K *__restrict__ keys,
+	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs)
+{
+	using C = Cfg<K, V>;
+	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, CAP = TH * KPT;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	K *xk = reinterpret_cast<K *>(smem);
+	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * (sizeof(K) + 8)); // two 16-bit counters per word
+	uint32_t *wtot = cw + ((size_t)1 << kPairCountBits) / 2;
+	if (blockIdx.x >= nsegs) return;
+	const Segment sg = segs[blockIdx.x];
+	const uint32_t n = (uint32_t)sg.count, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t nv = 1u << sg.bits, mask = nv - 1u, nwords = nv >= 2 ? nv / 2 : 1;
+	for (uint32_t j = tid; j < nwords; j += TH) cw[j] = 0;
+	K kr[KPT];
+	uint64_t vr[KPT];
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) {
+		const uint32_t idx = i * TH + tid;
+		kr[i] = 0;
+		vr[i] = 0;
+		if (idx < n) {
+			kr[i] = keys[sg.start + idx];
+			vr[i] = vals[sg.start + idx];
+		}
+	}
+	__syncthreads();
+	uint32_t rk[KPT];
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) {
+		rk[i] = 0;
+		if ((uint32_t)(i * TH) + tid < n) {
+			const uint32_t v = (uint32_t)kr[i] & mask, sh = 16u * (v & 1u);
+			rk[i] = (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu;
+		}
+	}
+	__syncthreads();
+	// counts -> exclusive positions, in place; thread t owns words [t*wpt, (t+1)*wpt)
+	const uint32_t wpt = nwords >= (uint32_t)TH ? nwords / TH : 1;
+	const uint32_t w0 = tid * wpt;
+	uint32_t tot = 0;
+	if (w0 < nwords)
+		for (uint32_t j = 0; j < wpt; ++j) {
+			const uint32_t x = cw[w0 + j];
+			tot += (x & 0xFFFFu) + (x >> 16);
+		}
+	const uint32_t inc = wave_incl_scan(tot);
+	if (lane == 63) wtot[w] = inc;
+	__syncthreads();
+	uint32_t run = inc - tot;
+	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
+	if (w0 < nwords)
+		for (uint32_t j = 0; j < wpt; ++j) {
+			const uint32_t x = cw[w0 + j];
+			const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
+			cw[w0 + j] = run | ((run + lo) << 16);
+			run += lo + hi;
+		}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) {
+		if ((uint32_t)(i * TH) + tid < n) {
+			const uint32_t v = (uint32_t)kr[i] & mask;
+			const uint32_t p = ((cw[v >> 1] >> (16u * (v & 1u))) & 0xFFFFu) + rk[i];
+			xk[p] = kr[i];
+			xv[p] = vr[i];
+		}
+	}
+	__syncthreads();
+	for (uint32_t idx = tid; idx < n; idx += TH) {
+		keys[sg.start + idx] = xk[idx];
+		vals[sg.start + idx] = xv[idx];
+	}
+}
+
 // ------------------------------------- counting sort for segments of any size
 
 // Keys-only segments with <= 16 open bits that do not fit LDS: every tile of a segment counts its

@@ -437,7 +437,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	Segment *small = c->lists, *small_count = c->lists + 2 * c->lists_cap;
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 	// keys without payload whose last <= 16 bits are open are finished by the counting sort
-	const uint32_t count_bits = HV ? 0u : (uint32_t)kCountMaxBits;
+	const uint32_t count_bits = HV ? (uint32_t)kPairCountBits : (uint32_t)kCountMaxBits;
 
 	// ---- leading-bit skipping: a cheap strided sample decides whether an exact OR/AND pass over
 	// all keys can pay off (it does when whole leading digits are constant, e.g. keys whose upper
@@ -613,6 +613,15 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 	// ---- leaves, stage 1: one unstable counting pass over all remaining bits (one workgroup per segment)
 	constexpr size_t sort_lds = SortLds<K, V>::bytes;
+	if constexpr (HV) {
+		if (ncount_host && !single_pass) { // tuples: counting leaf with payload (cannot overflow, no fallback)
+			constexpr size_t pair_lds = PairCountLds<K, V>::bytes;
+			hipLaunchKernelGGL((pair_count_sort_kernel<K, V>), dim3(ncount_host), dim3(C::SORT_TH), pair_lds, c->stream,
+					   keys, vals, small_count, ncount_host);
+			HIPCHK(c, hipGetLastError());
+			phase_mark(c, "count sort");
+		}
+	}
 	if constexpr (!HV) {
 		if (ncount_host && !single_pass) {
 			hipLaunchKernelGGL((count_sort_kernel<K>), dim3(ncount_host), dim3(kCountTh), kCountLds, c->stream,
@@ -688,7 +697,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					   keys, vals, small, nsmall_host, (const uint32_t *)nullptr);
 			HIPCHK(c, hipGetLastError());
 		}
-		if (ncount_host) { // counting-sort overflows (count only known on the device)
+		if (ncount_host && !HV) { // counting-sort overflows (count only known on the device)
 			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(std::min<uint32_t>(ncount_host, 2 * c->sm_count)), dim3(C::SORT_TH), sort_lds, c->stream,
 					   keys, vals, small + nsmall_host, 0u, (const uint32_t *)&ctr->nfallback);
 			HIPCHK(c, hipGetLastError());
@@ -708,6 +717,9 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
+	if constexpr (has_val<V>::value)
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_count_sort_kernel<K, V>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_sort_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
@@ -956,7 +968,7 @@ static int plan_describe(uint64_t n, int end_bit, int cus, msd_plan *out)
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
 	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
-	const uint32_t count_bits = HV ? 0u : (uint32_t)kCountMaxBits;
+	const uint32_t count_bits = HV ? (uint32_t)kPairCountBits : (uint32_t)kCountMaxBits;
 	memset(out, 0, sizeof *out);
 	out->block_elems = C::B;
 	out->tile_elems = C::T;

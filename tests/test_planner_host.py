@@ -28,7 +28,7 @@ def test_u32_plans_leave_at_most_16_open_bits_or_fit_lds(n):
 
 def test_pairs_and_u64_plans():
     p = plan_first_round(1 << 30, 8, 8)
-    assert p["digit_width"] == 8 and p["digit_shift"] == 56 and p["block_elems"] * 8 == 256 and p["leaf_count_bits"] == 0
+    assert p["digit_width"] == 8 and p["digit_shift"] == 56 and p["block_elems"] * 8 == 256 and p["leaf_count_bits"] == 14
     assert p["expected_rounds"] == 3                          # 16 Ki-pair segments exceed the pair leaf capacity
     q = plan_first_round(1 << 30, 8, 8, end_bit=32)           # config 5b after leading-bit skipping
     assert q["digit_shift"] == 24 and q["expected_rounds"] == 3
