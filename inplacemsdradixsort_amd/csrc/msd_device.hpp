@@ -1042,92 +1042,164 @@ __global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ ke
 	}
 }
 
-// --------------------------------------- one-pass counting leaf with payload
+// ------------------------------------------- counting leaf (keys or tuples)
 
-// (key, rid) segments that fit the LDS exchange buffers and have <= 14 open bits: one unstable
-// counting pass over all open bits.  16-bit counters (a segment has < 65536 tuples, so they cannot
-// overflow) are bumped by LDS fetch-adds whose return value is the tuple's rank among equal keys;
-// an in-place scan turns counts into positions; tuples are scattered into LDS and stored coalesced.
-constexpr int kPairCountBits = 14;
-template <typename K, typename V> struct PairCountLds {
+// Leaf for segments that fit the LDS exchange buffers: ONE unstable counting pass over the top 14
+// of the bits that actually vary in the segment.  16-bit counters (a segment has < 65536 elements,
+// so they cannot overflow) are bumped by LDS fetch-adds whose return value is the element's rank
+// among equal counted values; an in-place scan turns counts into positions; elements are scattered
+// into LDS.  If more than 14 bits vary, the few groups of equal counted bits are put in order by
+// whole-key insertion (their first element does it); a group longer than 48 sends the untouched
+// segment to the general LDS sort.  Output is stored coalesced.
+constexpr int kLeafCountBits = 14;
+template <typename K, typename V> struct LeafCountLds {
 	static constexpr int CAP = Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT;
-	static constexpr size_t bytes = (size_t)CAP * (sizeof(K) + 8) + ((size_t)1 << kPairCountBits) * 2 + 128;
+	static constexpr size_t bytes = (size_t)CAP * (sizeof(K) + (has_val<V>::value ? 8 : 0)) +
+					((size_t)1 << kLeafCountBits) * 2 + 192;
 };
 
 template <typename K, typename V>
-__global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void pair_count_sort_kernel(K *__restrict__ keys,
-	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs)
+__global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K *__restrict__ keys,
+	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs,
+	Segment *__restrict__ fallback, Counters *__restrict__ ctr)
 {
 	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
 	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, CAP = TH * KPT;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	K *xk = reinterpret_cast<K *>(smem);
 	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
-	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * (sizeof(K) + 8)); // two 16-bit counters per word
-	uint32_t *wtot = cw + ((size_t)1 << kPairCountBits) / 2;
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * (sizeof(K) + (HV ? 8 : 0))); // 2 x 16-bit counters per word
+	uint32_t *wtot = cw + ((size_t)1 << kLeafCountBits) / 2; // 16 wave totals, [16] flag
+	K *s_or = reinterpret_cast<K *>(wtot + 32);              // [2] OR / AND of the keys
 	if (blockIdx.x >= nsegs) return;
 	const Segment sg = segs[blockIdx.x];
 	const uint32_t n = (uint32_t)sg.count, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const uint32_t nv = 1u << sg.bits, mask = nv - 1u, nwords = nv >= 2 ? nv / 2 : 1;
-	for (uint32_t j = tid; j < nwords; j += TH) cw[j] = 0;
 	K kr[KPT];
-	uint64_t vr[KPT];
+	uint64_t vr[HV ? KPT : 1];
+	K k_or = 0, k_and = ~(K)0;
 #pragma unroll
 	for (int i = 0; i < KPT; ++i) {
 		const uint32_t idx = i * TH + tid;
 		kr[i] = 0;
-		vr[i] = 0;
+		if constexpr (HV) vr[i] = 0;
 		if (idx < n) {
 			kr[i] = keys[sg.start + idx];
-			vr[i] = vals[sg.start + idx];
+			if constexpr (HV) vr[i] = vals[sg.start + idx];
+			k_or |= kr[i];
+			k_and &= kr[i];
+		}
+	}
+	if (tid == 0) {
+		s_or[0] = 0;
+		s_or[1] = ~(K)0;
+		wtot[16] = 0;
+	}
+	for (uint32_t j = tid; j < ((uint32_t)1 << kLeafCountBits) / 2; j += TH) cw[j] = 0;
+	__syncthreads();
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		k_or |= __shfl_xor(k_or, o);
+		k_and &= __shfl_xor(k_and, o);
+	}
+	if (lane == 0) {
+		if constexpr (sizeof(K) == 4) {
+			atomicOr(reinterpret_cast<unsigned int *>(&s_or[0]), (unsigned int)k_or);
+			atomicAnd(reinterpret_cast<unsigned int *>(&s_or[1]), (unsigned int)k_and);
+		} else {
+			atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
+			atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
 		}
 	}
 	__syncthreads();
+	const K openmask = sg.bits >= sizeof(K) * 8 ? ~(K)0 : (((K)1 << sg.bits) - 1);
+	const K vopen = (s_or[0] ^ s_or[1]) & openmask;
+	if (vopen == 0) return; // constant on the open bits: already sorted
+	const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
+	const uint32_t shift = nbits > (uint32_t)kLeafCountBits ? nbits - kLeafCountBits : 0;
+	const uint32_t mask = (1u << (nbits - shift)) - 1u;
 	uint32_t rk[KPT];
 #pragma unroll
 	for (int i = 0; i < KPT; ++i) {
 		rk[i] = 0;
 		if ((uint32_t)(i * TH) + tid < n) {
-			const uint32_t v = (uint32_t)kr[i] & mask, sh = 16u * (v & 1u);
+			const uint32_t v = (uint32_t)(kr[i] >> shift) & mask, sh = 16u * (v & 1u);
 			rk[i] = (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu;
 		}
 	}
 	__syncthreads();
-	// counts -> exclusive positions, in place; thread t owns words [t*wpt, (t+1)*wpt)
-	const uint32_t wpt = nwords >= (uint32_t)TH ? nwords / TH : 1;
-	const uint32_t w0 = tid * wpt;
+	// counts -> exclusive positions, in place; thread t owns 8 words
+	constexpr uint32_t WPT = (((uint32_t)1 << kLeafCountBits) / 2) / TH;
+	static_assert(WPT >= 1, "counter words per thread");
+	const uint32_t w0 = tid * WPT;
 	uint32_t tot = 0;
-	if (w0 < nwords)
-		for (uint32_t j = 0; j < wpt; ++j) {
-			const uint32_t x = cw[w0 + j];
-			tot += (x & 0xFFFFu) + (x >> 16);
-		}
+#pragma unroll
+	for (uint32_t j = 0; j < WPT; ++j) {
+		const uint32_t x = cw[w0 + j];
+		tot += (x & 0xFFFFu) + (x >> 16);
+	}
 	const uint32_t inc = wave_incl_scan(tot);
 	if (lane == 63) wtot[w] = inc;
 	__syncthreads();
 	uint32_t run = inc - tot;
 	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
-	if (w0 < nwords)
-		for (uint32_t j = 0; j < wpt; ++j) {
-			const uint32_t x = cw[w0 + j];
-			const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
-			cw[w0 + j] = run | ((run + lo) << 16);
-			run += lo + hi;
-		}
+#pragma unroll
+	for (uint32_t j = 0; j < WPT; ++j) {
+		const uint32_t x = cw[w0 + j];
+		const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
+		cw[w0 + j] = run | ((run + lo) << 16);
+		run += lo + hi;
+	}
 	__syncthreads();
 #pragma unroll
 	for (int i = 0; i < KPT; ++i) {
 		if ((uint32_t)(i * TH) + tid < n) {
-			const uint32_t v = (uint32_t)kr[i] & mask;
+			const uint32_t v = (uint32_t)(kr[i] >> shift) & mask;
 			const uint32_t p = ((cw[v >> 1] >> (16u * (v & 1u))) & 0xFFFFu) + rk[i];
 			xk[p] = kr[i];
-			xv[p] = vr[i];
+			if constexpr (HV) xv[p] = vr[i];
 		}
 	}
 	__syncthreads();
+	if (shift) { // more bits vary than were counted: order the groups of equal counted bits by whole keys
+		const K lowmask = ((K)1 << shift) - 1;
+		bool too_long = false;
+		if ((vopen & lowmask) != 0) {
+			for (uint32_t i = tid; i < n; i += TH) {
+				const K hi = xk[i] >> shift;
+				if ((i == 0 || (xk[i - 1] >> shift) != hi) && i + 1 < n && (xk[i + 1] >> shift) == hi) {
+					uint32_t e = i + 2;
+					while (e < n && (xk[e] >> shift) == hi) ++e;
+					if (e - i > 48) {
+						too_long = true;
+					} else {
+						for (uint32_t a = i + 1; a < e; ++a) {
+							const K ka = xk[a];
+							uint64_t va = 0;
+							if constexpr (HV) va = xv[a];
+							uint32_t b = a;
+							while (b > i && xk[b - 1] > ka) {
+								xk[b] = xk[b - 1];
+								if constexpr (HV) xv[b] = xv[b - 1];
+								--b;
+							}
+							xk[b] = ka;
+							if constexpr (HV) xv[b] = va;
+						}
+					}
+				}
+			}
+		}
+		if (too_long) wtot[16] = 1;
+		__syncthreads();
+		if (wtot[16]) { // nothing has been written back yet: the general LDS sort takes the segment as it is
+			if (tid == 0) fallback[atomicAdd(&ctr->nfallback, 1u)] = sg;
+			return;
+		}
+	}
 	for (uint32_t idx = tid; idx < n; idx += TH) {
 		keys[sg.start + idx] = xk[idx];
-		vals[sg.start + idx] = xv[idx];
+		if constexpr (HV) vals[sg.start + idx] = xv[idx];
 	}
 }
 

@@ -29,7 +29,7 @@ struct msd_ctx {
 	size_t slab_bytes = 0;
 	char *keep = nullptr; // device workspace that lives for the whole call
 	size_t keep_bytes = 0;
-	Segment *lists = nullptr; // leaf-segment lists: [general: 2*cap][counting sort: cap]
+	Segment *lists = nullptr; // leaf-segment lists: [general + fallbacks behind it: 3*cap][counting sort: cap]
 	size_t lists_cap = 0;
 	void *pinned = nullptr; // small host staging (pinned)
 	size_t pinned_bytes = 0;
@@ -111,12 +111,12 @@ static int lists_reserve(msd_ctx *c, size_t need, size_t live_general, size_t li
 	if (need <= c->lists_cap) return MSD_OK;
 	const size_t cap = align_up(need + need / 2, 4096);
 	Segment *nb = nullptr;
-	hipError_t e = hipMalloc((void **)&nb, 3 * cap * sizeof(Segment));
+	hipError_t e = hipMalloc((void **)&nb, 4 * cap * sizeof(Segment));
 	if (e != hipSuccess) return fail(c, MSD_ENOMEM, "leaf list hipMalloc failed: %s", hipGetErrorString(e));
 	if (c->lists) {
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		if (live_general) HIPCHK(c, hipMemcpy(nb, c->lists, live_general * sizeof(Segment), hipMemcpyDeviceToDevice));
-		if (live_count) HIPCHK(c, hipMemcpy(nb + 2 * cap, c->lists + 2 * c->lists_cap, live_count * sizeof(Segment), hipMemcpyDeviceToDevice));
+		if (live_count) HIPCHK(c, hipMemcpy(nb + 3 * cap, c->lists + 3 * c->lists_cap, live_count * sizeof(Segment), hipMemcpyDeviceToDevice));
 		HIPCHK(c, hipFree(c->lists));
 	}
 	c->lists = nb;
@@ -434,10 +434,10 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	Counters *ctr = kb.take<Counters>(2);
 	const uint32_t big_cap = (uint32_t)std::min<uint64_t>(n / small_max + 16, 0x7FFFFFFFu);
 	Segment *big = kb.take<Segment>(big_cap);
-	Segment *small = c->lists, *small_count = c->lists + 2 * c->lists_cap;
+	Segment *small = c->lists, *small_count = c->lists + 3 * c->lists_cap;
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 	// keys without payload whose last <= 16 bits are open are finished by the counting sort
-	const uint32_t count_bits = HV ? (uint32_t)kPairCountBits : (uint32_t)kCountMaxBits;
+	const uint32_t count_bits = HV ? (uint32_t)kLeafCountBits : (uint32_t)kCountMaxBits;
 
 	// ---- leading-bit skipping: a cheap strided sample decides whether an exact OR/AND pass over
 	// all keys can pay off (it does when whole leading digits are constant, e.g. keys whose upper
@@ -517,7 +517,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			int rc = lists_reserve(c, (size_t)std::max(nsmall_host, ncount_host) + nc + 16, nsmall_host, ncount_host);
 			if (rc) return rc;
 			small = c->lists;
-			small_count = c->lists + 2 * c->lists_cap;
+			small_count = c->lists + 3 * c->lists_cap;
 		}
 		const uint32_t small_cap = (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu);
 		if (round > 0) HIPCHK(c, hipMemsetAsync(ctr, 0, 3 * sizeof(uint32_t), c->stream)); // nholes, hole_cursor, next_parents
@@ -613,15 +613,6 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 	// ---- leaves, stage 1: one unstable counting pass over all remaining bits (one workgroup per segment)
 	constexpr size_t sort_lds = SortLds<K, V>::bytes;
-	if constexpr (HV) {
-		if (ncount_host && !single_pass) { // tuples: counting leaf with payload (cannot overflow, no fallback)
-			constexpr size_t pair_lds = PairCountLds<K, V>::bytes;
-			hipLaunchKernelGGL((pair_count_sort_kernel<K, V>), dim3(ncount_host), dim3(C::SORT_TH), pair_lds, c->stream,
-					   keys, vals, small_count, ncount_host);
-			HIPCHK(c, hipGetLastError());
-			phase_mark(c, "count sort");
-		}
-	}
 	if constexpr (!HV) {
 		if (ncount_host && !single_pass) {
 			hipLaunchKernelGGL((count_sort_kernel<K>), dim3(ncount_host), dim3(kCountTh), kCountLds, c->stream,
@@ -690,15 +681,26 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 	set_stat(c, "big_count_segments", nbig_host);
 
-	// ---- leaves, stage 2: the general LDS sort (payloads, > 16 open bits, counting-sort overflows)
+	// ---- leaves, stage 2: everything else that fits LDS (payloads, > 16 open bits): counting leaf on the
+	// top varying bits; its rare failures (long groups of equal top bits) and the byte-counter overflows
+	// of stage 1 go to the general LDS sort (their number is only known on the device)
 	if (!single_pass) {
+		const uint32_t nsm = nsmall_host + (HV ? ncount_host : 0u); // tuples: both lists hold leaf_count work
 		if (nsmall_host) {
-			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), sort_lds, c->stream,
-					   keys, vals, small, nsmall_host, (const uint32_t *)nullptr);
+			constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
+			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), leaf_lds, c->stream,
+					   keys, vals, small, nsmall_host, small + nsmall_host, ctr);
 			HIPCHK(c, hipGetLastError());
 		}
-		if (ncount_host && !HV) { // counting-sort overflows (count only known on the device)
-			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(std::min<uint32_t>(ncount_host, 2 * c->sm_count)), dim3(C::SORT_TH), sort_lds, c->stream,
+		if (HV && ncount_host) {
+			constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
+			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(ncount_host), dim3(C::SORT_TH), leaf_lds, c->stream,
+					   keys, vals, small_count, ncount_host, small + nsmall_host, ctr);
+			HIPCHK(c, hipGetLastError());
+		}
+		(void)nsm;
+		if (nsmall_host + ncount_host) {
+			hipLaunchKernelGGL((lds_sort_kernel<K, V>), dim3(std::min<uint32_t>(nsmall_host + ncount_host, 2 * c->sm_count)), dim3(C::SORT_TH), sort_lds, c->stream,
 					   keys, vals, small + nsmall_host, 0u, (const uint32_t *)&ctr->nfallback);
 			HIPCHK(c, hipGetLastError());
 		}
@@ -706,7 +708,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 	set_stat(c, "count_segments", ncount_host);
 	set_stat(c, "small_segments", nsmall_host);
-	set_stat(c, "workspace_bytes", c->slab_bytes + c->keep_bytes + 3 * c->lists_cap * sizeof(Segment));
+	set_stat(c, "workspace_bytes", c->slab_bytes + c->keep_bytes + 4 * c->lists_cap * sizeof(Segment));
 	phase_end(c);
 	return MSD_OK;
 }
@@ -717,9 +719,8 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
-	if constexpr (has_val<V>::value)
-		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&pair_count_sort_kernel<K, V>),
-					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PairCountLds<K, V>::bytes));
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_sort_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
@@ -813,7 +814,7 @@ int msd_reserve(msd_ctx *c, uint64_t n, int key_bytes, int val_bytes)
 	return rc;
 }
 
-uint64_t msd_workspace_bytes(const msd_ctx *c) { return c ? c->slab_bytes + c->keep_bytes + 3 * c->lists_cap * sizeof(Segment) : 0; }
+uint64_t msd_workspace_bytes(const msd_ctx *c) { return c ? c->slab_bytes + c->keep_bytes + 4 * c->lists_cap * sizeof(Segment) : 0; }
 const char *msd_last_error(const msd_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
 int msd_sort_u32_bits(msd_ctx *c, uint32_t *k, uint64_t n, int end_bit)
@@ -968,7 +969,7 @@ static int plan_describe(uint64_t n, int end_bit, int cus, msd_plan *out)
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
 	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
-	const uint32_t count_bits = HV ? (uint32_t)kPairCountBits : (uint32_t)kCountMaxBits;
+	const uint32_t count_bits = HV ? (uint32_t)kLeafCountBits : (uint32_t)kCountMaxBits;
 	memset(out, 0, sizeof *out);
 	out->block_elems = C::B;
 	out->tile_elems = C::T;
@@ -993,7 +994,7 @@ static int plan_describe(uint64_t n, int end_bit, int cus, msd_plan *out)
 		++rounds;
 	}
 	out->expected_rounds = rounds;
-	out->workspace_bytes = round_bytes_estimate<K, V>(n, cus) + keep_bytes_for<K, V>(n) + 3 * leaf_list_guess<K, V>(n) * sizeof(Segment);
+	out->workspace_bytes = round_bytes_estimate<K, V>(n, cus) + keep_bytes_for<K, V>(n) + 4 * leaf_list_guess<K, V>(n) * sizeof(Segment);
 	return MSD_OK;
 }
 
