@@ -128,6 +128,14 @@ typedef struct msd_plan {
 } msd_plan;
 int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, int compute_units, msd_plan *out);
 
+/* ---- tuning knobs (no counterpart in the reference) --------------------------------
+ * "direct_mode": 0 = every round classifies into the workgroup's own stripe and permutes
+ *   all blocks afterwards; 1 (default) = the first round of a large input whose sampled
+ *   top-digit buckets are about equally big writes its blocks straight into the bucket's
+ *   estimated region and permutes only the misplaced ones; 2 = the same without the sample test.
+ * "direct_min": smallest input (elements) direct placement is tried on (default 2^26). */
+int msd_set_option(msd_ctx *ctx, const char *name, int64_t value);
+
 /* ---- phase report (reference: description[]/times[], src/msb_64.c:2402-2412) */
 
 /* Enable per-phase hipEvent timing for subsequent sorts on this context

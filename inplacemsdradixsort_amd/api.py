@@ -137,6 +137,10 @@ class MsdContext:
     def gen_iota_u64(self, vals, first: int = 0) -> None:
         self._ok(self._L.msd_gen_iota_u64(self._h, self._ptr(vals, 8), vals.numel(), first))
 
+    def set_option(self, name: str, value: int) -> None:
+        """Tuning knob of include/msd_radix_hip.h (``direct_mode``, ``direct_min``)."""
+        self._ok(self._L.msd_set_option(self._h, name.encode(), int(value)))
+
     # ---- phase report
     def set_profiling(self, on: bool) -> None:
         self._ok(self._L.msd_set_profiling(self._h, int(on)))
@@ -148,7 +152,7 @@ class MsdContext:
     def stats(self) -> Dict[str, int]:
         out = {}
         for name in ("rounds", "parents", "stripes", "children", "slots", "holes", "chain_steps",
-                     "small_segments", "count_segments", "big_count_segments", "skipped_bits", "workspace_bytes"):
+                     "small_segments", "count_segments", "big_count_segments", "direct_rounds", "skipped_bits", "workspace_bytes"):
             v = C.c_uint64()
             if self._L.msd_stat(self._h, name.encode(), C.byref(v)) == 0:
                 out[name] = int(v.value)

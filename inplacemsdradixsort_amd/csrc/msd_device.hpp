@@ -93,7 +93,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t ncount;       // cumulative: segments for the one-pass counting sort (<= 16 bits left)
 	uint32_t nfallback;    // counting-sort segments handed to the general LDS sort (byte counter overflow)
 	uint32_t nbig;         // cumulative: segments of any size with <= 16 bits left (multi-workgroup counting sort)
-	uint32_t pad[3];
+	uint32_t count_ticket; // work ticket of the persistent counting-sort workgroups
+	uint32_t pad[2];
 };
 
 // ---------------------------------------------------------------- utilities
@@ -453,6 +454,474 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 	}
 }
 
+// ------------------------------------ A': classify with direct block placement
+
+// Experimental variant of phase A for a single large parent whose children are about equally big.
+// A strided sample estimates the child boundaries; every workgroup owns, for each child, a *piece*
+// (run of slots) of that child's estimated region and reads its pieces round-robin, one 256-byte
+// slot per piece per row.  A completed block goes straight into the workgroup's own piece of the
+// block's child whenever that piece has a slot that was already read ("write behind read" holds
+// per piece); otherwise it takes any read slot of the workgroup (misplaced).  Slots that stay
+// unwritten are empty.  The block permutation (B) then only has to fix misplaced / empty slots.
+struct DirectPlan {
+	uint32_t est_cnt[kP];   // sampled digit counts
+	uint32_t bound[kP + 1]; // estimated child boundaries in slots (bound[0] = first slot of the parent)
+};
+
+template <typename K>
+__global__ __launch_bounds__(256) void direct_sample_kernel(const K *__restrict__ keys, const Parent *__restrict__ parents,
+	DirectPlan *__restrict__ plan, uint32_t every)
+{
+	__shared__ uint32_t h[kP];
+	const Parent pa = parents[0];
+	const uint32_t mask = (1u << pa.width) - 1u;
+	h[threadIdx.x] = 0;
+	__syncthreads();
+	// every `every`-th run of 256 consecutive keys (coalesced), four runs in flight per thread
+	const uint64_t nruns = pa.count / 256;
+	const uint64_t step = (uint64_t)gridDim.x * every;
+	for (uint64_t r = (uint64_t)blockIdx.x * every; r < nruns; r += 4 * step) {
+		K k4[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (r + u * step < nruns) k4[u] = keys[pa.start + (r + u * step) * 256 + threadIdx.x];
+#pragma unroll
+		for (int u = 0; u < 4; ++u)
+			if (r + u * step < nruns) atomicAdd(&h[digit_of(k4[u], pa.shift, mask)], 1u);
+	}
+	__syncthreads();
+	if (h[threadIdx.x]) atomicAdd(&plan->est_cnt[threadIdx.x], h[threadIdx.x]);
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restrict__ parents, DirectPlan *__restrict__ plan)
+{
+	__shared__ uint64_t tmp[8];
+	const Parent pa = parents[0];
+	const uint32_t d = threadIdx.x;
+	const uint64_t s0 = (pa.start + B - 1) / B, s1 = (pa.start + pa.count) / B; // aligned slots of the parent
+	uint64_t total;
+	const uint64_t c = plan->est_cnt[d];
+	const uint64_t ex = block_excl_scan256_64(c, tmp, total);
+	const uint64_t ns = s1 > s0 ? s1 - s0 : 0;
+	plan->bound[d] = (uint32_t)(s0 + (total ? ex * ns / total : (uint64_t)d * ns / kP));
+	if (d == 0) plan->bound[kP] = (uint32_t)s1;
+}
+
+template <typename K, typename V> struct DirectLds {
+	using C = Cfg<K, V>;
+	static constexpr bool HV = has_val<V>::value;
+	static constexpr size_t kbuf = (size_t)(kP * C::B) * sizeof(K);
+	static constexpr size_t vbuf = HV ? (size_t)(kP * C::B) * sizeof(uint64_t) : 0;
+	static constexpr size_t head = (size_t)2 * C::B * sizeof(K) + (HV ? (size_t)2 * C::B * sizeof(uint64_t) : 0);
+	static constexpr int JOBS = kP; // at most one buffer per bucket and tile
+	static constexpr int XT = 128;
+	static constexpr int SEL = 64; // slots read per tile (upper bound over the configurations)
+	// meta, cnt, hc, loff, plo, cw, pnl, bst, fbc, rot : 10*kP u32 ; jobs (2 words each) ; xtab ; sel ; tmp
+	static constexpr size_t small = (size_t)(10 * kP + 2 * JOBS + 2 * XT + SEL + 32) * sizeof(uint32_t);
+	static constexpr size_t bytes = kbuf + vbuf + head + small;
+};
+
+// The `need` lanes with the smallest 10-bit value among the eligible ones (ties: lower lane first).
+// Wave-uniform radix select on ballots; returns this lane's verdict, `mask_out` = all selected lanes.
+__device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int need, uint64_t &mask_out)
+{
+	uint64_t cand = __ballot(elig), selm = 0;
+	if (__popcll(cand) > need) {
+#pragma unroll
+		for (int bit = 9; bit >= 0; --bit) {
+			const uint64_t zeros = cand & ~__ballot((v >> bit) & 1u);
+			const int cz = __popcll(zeros);
+			if (cz >= need)
+				cand = zeros;
+			else {
+				selm |= zeros;
+				need -= cz;
+				cand &= ~zeros;
+			}
+		}
+		// the candidates left are equal: the lowest `need` lanes of them
+		const uint32_t lane = threadIdx.x & 63;
+		const bool mine = ((cand >> lane) & 1ull) && __popcll(cand & ((1ull << lane) - 1ull)) < need;
+		selm |= __ballot(mine);
+	} else
+		selm = cand;
+	mask_out = selm;
+	return (selm >> (threadIdx.x & 63)) & 1ull;
+}
+
+template <typename K, typename V>
+__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) void classify_direct_kernel(
+	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
+	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plan, uint8_t *__restrict__ block_map,
+	uint8_t *__restrict__ slot_full, uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt,
+	uint32_t *__restrict__ lo_off, K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals,
+	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr)
+{
+	using C = Cfg<K, V>;
+	constexpr bool HV = has_val<V>::value;
+	constexpr int B = C::B, TH = C::TH;
+	constexpr int VEC = Vec16<K>::N;
+	constexpr int LPB = B / VEC;       // lanes per slot (16)
+	constexpr int GPT = TH / LPB;      // slots read per tile (64 for 1024 threads)
+	constexpr int SPW = GPT / 4;       // slots each of the 4 bucket waves may request per tile
+	constexpr int KPT = VEC;           // one 16-byte vector per thread per tile
+	constexpr int PB = kP * B;
+	constexpr uint32_t NONE = 0xFFFFFFFFu;
+	static_assert(GPT % 4 == 0 && GPT <= DirectLds<K, V>::SEL, "tile geometry");
+	using L = DirectLds<K, V>;
+
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	// the small arrays come first: their LDS addresses then fit the 16-bit offset field of the DS
+	// instructions (one address register for all of them)
+	uint32_t *meta = reinterpret_cast<uint32_t *>(smem);
+	uint64_t *headv = reinterpret_cast<uint64_t *>(smem + L::small);
+	K *headk = reinterpret_cast<K *>(smem + L::small + (HV ? (size_t)2 * B * sizeof(uint64_t) : 0));
+	K *kbuf = reinterpret_cast<K *>(smem + L::small + L::head);
+	uint64_t *vbuf = reinterpret_cast<uint64_t *>(smem + L::small + L::head + L::kbuf);
+	uint32_t *cnt = meta + kP;
+	uint32_t *hc = cnt + kP;
+	uint32_t *loff = hc + kP;
+	uint32_t *plo = loff + kP;     // first slot of my piece of child d
+	uint32_t *cw = plo + kP;       // slots of the piece consumed (low 16) | blocks written into it (high 16)
+	uint32_t *pnl = cw + kP;       // slots in the piece
+	uint32_t *bst = pnl + kP;      // bucket state: reads issued (low 16) | in-flight bits (16..17) | buffer fill (18..)
+	uint32_t *fbc = bst + kP;      // full blocks produced
+	uint32_t *rot = fbc + kP;      // the piece is used from slot rot[d] on, wrapping around (see phys)
+	uint32_t *jobs = rot + kP;     // [2*g] bucket, [2*g+1] destination slot
+	uint32_t *xtab = jobs + 2 * L::JOBS; // (bucket<<16 | q) -> slot for the extra blocks of skewed tiles
+	uint32_t *sel = xtab + 2 * L::XT;    // slots to read for the tile after next
+	uint32_t *tmp = sel + L::SEL;  // [0..1] jobs per tile (ping-pong) [2..3] xtab fill [6..7] steal flag [12..15] reads selected [8..] scan scratch (epilogue)
+
+	const uint32_t tid = threadIdx.x, grp = tid / LPB, sub = tid % LPB, lane = tid & 63;
+	const Stripe st = stripes[blockIdx.x];
+	const Parent pa = parents[st.parent];
+	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u;
+	const uint32_t W = pa.stripe_hi - pa.stripe_lo, me = blockIdx.x - pa.stripe_lo;
+	const uint32_t slot0 = plan->bound[0], slotN = plan->bound[kP];
+
+	// per-bucket state lives in LDS (thread d < kP is the only one to touch bst/fbc of bucket d)
+	if (tid < kP) {
+		const uint32_t b0 = plan->bound[tid], b1 = plan->bound[tid + 1], len = b1 - b0;
+		const uint32_t p0 = b0 + (uint32_t)((uint64_t)me * len / W);
+		plo[tid] = p0;
+		pnl[tid] = b0 + (uint32_t)((uint64_t)(me + 1) * len / W) - p0;
+		// All workgroups advance through their pieces at about the same pace.  Were every piece used
+		// from its first slot on, the addresses in flight at any moment would agree in the bits that
+		// select the memory channel; a per-piece starting offset spreads them over all channels.
+		const uint32_t pn0 = b0 + (uint32_t)((uint64_t)(me + 1) * len / W) - p0;
+		rot[tid] = pn0 ? ((tid * 2654435761u) ^ (me * 40503u + (me >> 3))) % pn0 : 0u;
+		bst[tid] = 0;
+		fbc[tid] = 0;
+		cw[tid] = 0;
+		meta[tid] = 0;
+		cnt[tid] = 0;
+		hc[tid] = 0;
+	}
+	if (tid < 32) tmp[tid] = 0;
+	// head / tail keys of the parent (outside every aligned slot): first / last workgroup parks them
+	const uint64_t pend = pa.start + pa.count;
+	uint32_t h = 0;
+	if (me == 0) {
+		h = (uint32_t)((uint64_t)slot0 * B - pa.start);
+		if (tid < h) {
+			headk[tid] = keys[pa.start + tid];
+			if (HV) headv[tid] = vals[pa.start + tid];
+		}
+	}
+	uint32_t h2 = 0;
+	if (me == W - 1) {
+		h2 = (uint32_t)(pend - (uint64_t)slotN * B);
+		if (tid < h2) {
+			headk[h + tid] = keys[(uint64_t)slotN * B + tid];
+			if (HV) headv[h + tid] = vals[(uint64_t)slotN * B + tid];
+		}
+	}
+	const uint32_t hh = h + h2;
+	__syncthreads();
+	if (tid < hh) atomicAdd(&hc[digit_of(headk[tid], shift, mask)], 1u);
+	// A block written into piece d holds bucket d unless it was stolen by another bucket: mark the
+	// whole piece up front (64-byte runs), the rare stolen slot is overwritten when it is handed out;
+	// which slots hold a block at all (the first `written` of each piece) is recorded at the end.
+	for (uint32_t d = tid >> 6; d < (uint32_t)kP; d += TH / 64) {
+		const uint32_t p0 = plo[d], pn = pnl[d];
+		for (uint32_t j = lane; j < pn; j += 64) block_map[p0 + j] = (uint8_t)d;
+	}
+
+	// idx-th slot of piece d in the order the piece is used
+	auto phys = [&](uint32_t d, uint32_t idx) -> uint32_t {
+		const uint32_t pn = pnl[d];
+		uint32_t j = rot[d] + idx;
+		if (j >= pn) j -= pn;
+		return plo[d] + j;
+	};
+	// Which slots to read next: the pieces whose buckets have the least room (read-ahead slots plus
+	// free buffer space) go first, so that a bucket's next slot has been read before its buffer fills.
+	uint32_t rot_r = 0;
+	(void)rot_r;
+	auto select_reads = [&](uint32_t wr, uint32_t rd, uint32_t q, uint32_t fill, uint32_t *count_out) {
+		const bool elig = rd < pnl[tid];
+		const uint32_t v = min(1023u, (rd - wr) * B + B - fill);
+		uint64_t sm;
+#ifdef MSD_EXP_RR
+		(void)v;
+		const uint32_t rot = (rot_r++ & 3u) * SPW; // experiment: plain rotation, no selection
+		sm = __ballot(elig && ((lane - rot) & 63u) < (uint32_t)SPW);
+		const bool mine = (sm >> lane) & 1ull;
+#else
+		const bool mine = wave_select_smallest(v, elig, SPW, sm);
+#endif
+		const uint32_t n = (uint32_t)__popcll(sm), w = tid >> 6;
+		if (mine) {
+			sel[w * SPW + __popcll(sm & ((1ull << lane) - 1ull))] = phys(tid, rd);
+			++rd;
+			q |= 2; // bit0: has a slot in the next tile, bit1: in the tile after it
+		}
+		if (lane < (uint32_t)SPW && lane >= n) sel[w * SPW + lane] = NONE;
+		if (lane == 0 && n) atomicAdd(count_out, n);
+		bst[tid] = rd | (q << 16) | (fill << 18);
+	};
+	auto load_tile = [&](K *kr, uint64_t *vr) -> bool {
+		const uint32_t slot = sel[grp];
+		const bool ok = slot >= slot0 && slot < slotN; // NONE fails the test
+		if (ok) {
+			const uint64_t at = (uint64_t)slot * B + sub * VEC;
+			if constexpr (sizeof(K) == 4) {
+				const uint4 q = *reinterpret_cast<const uint4 *>(keys + at);
+				kr[0] = q.x; kr[1] = q.y; kr[2] = q.z; kr[3] = q.w;
+			} else {
+				const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + at);
+				kr[0] = q.x; kr[1] = q.y;
+			}
+			if constexpr (HV) {
+				const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + at);
+				vr[0] = q.x; vr[1] = q.y;
+			}
+		}
+		return ok;
+	};
+
+	K kreg[KPT], kregB[KPT];
+	uint64_t vreg[HV ? KPT : 1], vregB[HV ? KPT : 1];
+	K dkey[KPT];
+	uint64_t dval[HV ? KPT : 1];
+	uint32_t dat[KPT];
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) dat[i] = NONE;
+
+	// prologue: the first two tiles
+	if (tid < kP) {
+		select_reads(0, 0, 0, 0, &tmp[14]);
+		bst[tid] = (bst[tid] & 0xFFFFu) | (((bst[tid] >> 17) & 1u) << 16); // -> bit0: in tile 0
+	}
+	__syncthreads();
+	uint32_t nA = tmp[14];
+	bool okA = load_tile(kreg, vreg);
+	__syncthreads();
+	if (tid < kP) select_reads(0, bst[tid] & 0xFFFFu, (bst[tid] >> 16) & 3u, 0, &tmp[15]); // bit1: in tile 1
+	__syncthreads();
+	uint32_t nB = tmp[15];
+	bool okB = load_tile(kregB, vregB);
+	uint32_t par = 0;
+
+	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1], bool &okc, uint32_t &nc) {
+		// ---- ranks
+		uint32_t dr[KPT];
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			dr[i] = NONE;
+			if (okc) {
+				const uint32_t d = digit_of(kc[i], shift, mask);
+				dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
+			}
+		}
+		__syncthreads(); // B1
+		// ---- per bucket: completed blocks take a consumed slot of the bucket's own piece if there is one
+		uint32_t pend_blocks = 0, own_r = 0;
+		if (tid < kP) {
+			const uint32_t bs = bst[tid], fill0 = bs >> 18;
+			uint32_t q_r = (bs >> 16) & 3u;
+			const uint32_t L_r = fill0 + cnt[tid];
+			cnt[tid] = 0;
+			const uint32_t nb_r = L_r / B;
+			const uint32_t cwv = cw[tid], wr = cwv >> 16;
+			const uint32_t cons = (cwv & 0xFFFFu) + (q_r & 1u); // this tile's slot is now in registers
+			q_r >>= 1;
+			uint32_t own = 0;
+			if (nb_r) {
+				own = min(nb_r, cons - wr); // consecutive own slots plo+wr .. plo+wr+own-1
+				if (own) { // block 0 = the LDS buffer
+					const uint32_t j = atomicAdd(&tmp[par], 1u);
+					jobs[2 * j] = tid;
+					jobs[2 * j + 1] = phys(tid, wr);
+				}
+				pend_blocks = nb_r - own;
+				if (pend_blocks) tmp[6 + par] = 1;
+				fbc[tid] += nb_r;
+			}
+			cw[tid] = cons | ((wr + own) << 16);
+			meta[tid] = fill0 | (nb_r << 8) | (own << 20);
+			loff[tid] = wr; // first own destination (index into the piece) of this tile
+			own_r = own;
+			select_reads(wr + own, bs & 0xFFFFu, q_r, L_r - nb_r * B, &tmp[12 + par]);
+		}
+		if (tid == 0) {
+			tmp[par ^ 1] = 0;
+			tmp[2 + (par ^ 1)] = 0;
+			tmp[6 + (par ^ 1)] = 0;
+			tmp[12 + (par ^ 1)] = 0;
+		}
+		__syncthreads(); // B2a
+		if (tmp[6 + par]) { // (uniform) some bucket has no consumed slot left in its own piece: take one of another piece
+			for (uint32_t q = 0; q < pend_blocks; ++q) {
+				uint32_t slot = NONE, e = (tid * 37u + 1u) & (kP - 1);
+				for (uint32_t tries = 0; tries < 3 * kP; ++tries, e = (e + 1) & (kP - 1)) {
+					const uint32_t c0 = cw[e];
+					if ((c0 >> 16) >= (c0 & 0xFFFFu)) continue;
+					const uint32_t old = atomicAdd(&cw[e], 1u << 16);
+					if ((old >> 16) < (old & 0xFFFFu)) {
+						slot = phys(e, old >> 16);
+						break;
+					}
+					atomicSub(&cw[e], 1u << 16);
+				}
+				const uint32_t bi = own_r + q; // block index within this tile's run of the bucket
+				if (slot == NONE)
+					atomicAdd(&ctr->errors, 1u); // cannot happen: consumed slots >= blocks produced
+				else if (slot < slot0 || slot >= slotN)
+					atomicAdd(&ctr->errors, 1u);
+				else if (bi == 0) { // the bucket's LDS buffer
+					const uint32_t j = atomicAdd(&tmp[par], 1u);
+					jobs[2 * j] = tid;
+					jobs[2 * j + 1] = slot;
+					block_map[slot] = (uint8_t)tid;
+				} else {
+					const uint32_t x = atomicAdd(&tmp[2 + par], 1u);
+					if (x < (uint32_t)L::XT) {
+						xtab[2 * x] = (tid << 16) | bi;
+						xtab[2 * x + 1] = slot;
+						block_map[slot] = (uint8_t)tid;
+					} else
+						atomicAdd(&ctr->errors, 1u);
+				}
+			}
+			__syncthreads(); // B2b
+		}
+		const uint32_t nx = min(tmp[2 + par], (uint32_t)L::XT);
+		const uint32_t njobs = tmp[par];
+		// ---- scatter
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			if (dat[i] != NONE) {
+				kbuf[dat[i]] = dkey[i];
+				if constexpr (HV) vbuf[dat[i]] = dval[i];
+				dat[i] = NONE;
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < KPT; ++i) {
+			if (dr[i] != NONE) {
+				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
+				const uint32_t m = meta[d];
+				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
+				if (nb == 0 || vp < (uint32_t)B) {
+					kbuf[d * B + vp] = kc[i];
+					if constexpr (HV) vbuf[d * B + vp] = vc[i];
+				} else if (vp < nb * B) { // skewed tile: a further whole block of this bucket
+					const uint32_t q = vp / B, own = m >> 20;
+					uint32_t slot;
+					if (q < own)
+						slot = phys(d, loff[d] + q);
+					else {
+						slot = NONE;
+						for (uint32_t x = 0; x < nx; ++x)
+							if (xtab[2 * x] == ((d << 16) | q)) slot = xtab[2 * x + 1];
+					}
+					if (slot >= slot0 && slot < slotN) {
+						const uint64_t at = (uint64_t)slot * B + (vp - q * B);
+						keys[at] = kc[i];
+						if constexpr (HV) vals[at] = vc[i];
+					} else
+						atomicAdd(&ctr->errors, 1u);
+				} else {
+					dat[i] = d * B + vp - nb * B;
+					dkey[i] = kc[i];
+					if constexpr (HV) dval[i] = vc[i];
+				}
+			}
+		}
+		__syncthreads(); // B3
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		nc = tmp[12 + par];
+		okc = load_tile(kc, vc);
+		// ---- flush completed buffers to their slots
+		for (uint32_t g = grp; g < njobs; g += GPT) {
+			const uint32_t d = jobs[2 * g], slot = jobs[2 * g + 1];
+			if (slot >= slot0 && slot < slotN) {
+				const uint64_t dst = (uint64_t)slot * B + sub * VEC;
+				*reinterpret_cast<uint4 *>(keys + dst) = *reinterpret_cast<const uint4 *>(kbuf + d * B + sub * VEC);
+				if constexpr (HV)
+					*reinterpret_cast<uint4 *>(vals + dst) = *reinterpret_cast<const uint4 *>(vbuf + d * B + sub * VEC);
+			} else if (sub == 0)
+				atomicAdd(&ctr->errors, 1u);
+		}
+		par ^= 1;
+	};
+	for (;;) {
+		if (!nA) break;
+		tile(kreg, vreg, okA, nA);
+		if (!nB) break;
+		tile(kregB, vregB, okB, nB);
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < KPT; ++i) {
+		if (dat[i] != NONE) {
+			kbuf[dat[i]] = dkey[i];
+			if constexpr (HV) vbuf[dat[i]] = dval[i];
+		}
+	}
+	uint32_t fill_r = 0;
+	if (tid < kP) {
+		fill_r = bst[tid] >> 18;
+		meta[tid] = fill_r;
+	}
+	__syncthreads();
+	// ---- epilogue: leftovers (partial buffers + head/tail keys) to the side area
+	uint32_t lc = 0;
+	if (tid < kP) lc = fill_r + hc[tid];
+	uint32_t ltot;
+	const uint32_t lex = block_excl_scan256(lc, tmp + 8, ltot);
+	const size_t so = (size_t)blockIdx.x * kP + tid;
+	if (tid < kP) {
+		loff[tid] = lex;
+		lo_cnt[so] = lc;
+		lo_off[so] = lex;
+		fb[so] = fbc[tid];
+		hc[tid] = 0;
+	}
+	if (tid == 0) nfull[blockIdx.x] = 0;
+	__syncthreads();
+	for (uint32_t d = tid >> 6; d < (uint32_t)kP; d += TH / 64) {
+		const uint32_t p0 = plo[d], pn = pnl[d], wr = cw[d] >> 16, r0 = rot[d];
+		for (uint32_t j = lane; j < pn; j += 64) slot_full[p0 + j] = (j >= r0 ? j - r0 : j + pn - r0) < wr ? 1 : 0;
+	}
+	for (uint32_t idx = tid; idx < (uint32_t)PB; idx += TH) {
+		const uint32_t d = idx / B, j = idx % B;
+		if (j < (meta[d] & 0xFFu)) {
+			lo_keys[st.lo_base + loff[d] + j] = kbuf[idx];
+			if constexpr (HV) lo_vals[st.lo_base + loff[d] + j] = vbuf[idx];
+		}
+	}
+	if (tid < hh) {
+		const uint32_t d = digit_of(headk[tid], shift, mask);
+		const uint32_t r = atomicAdd(&hc[d], 1u);
+		const uint64_t at = st.lo_base + loff[d] + (meta[d] & 0xFFu) + r;
+		lo_keys[at] = headk[tid];
+		if constexpr (HV) lo_vals[at] = headv[tid];
+	}
+}
+
 // ------------------------------------------------- child geometry per parent
 
 struct ChildArrays {
@@ -550,12 +1019,14 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, const uint8_t *__restrict__ block_map,
 	const uint32_t *__restrict__ nfull, ChildArrays ca, ListEntry *__restrict__ list,
-	ListEntry *__restrict__ holes, Counters *__restrict__ ctr)
+	ListEntry *__restrict__ holes, Counters *__restrict__ ctr, const uint8_t *__restrict__ slot_full)
 {
+	// slot_full == nullptr: a stripe's first nfull slots hold blocks (streaming classify);
+	// otherwise a byte per slot says whether it holds a block (direct placement)
 	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP], s_base[2][kP];
 	const Stripe st = stripes[blockIdx.x];
 	const Parent pa = parents[st.parent];
-	const uint32_t W = 1u << pa.width, tid = threadIdx.x, lane = tid & 63;
+	const uint32_t W = 1u << pa.width, tid = threadIdx.x;
 	if (tid < W) {
 		s_is[tid] = ca.is[pa.child_base + tid];
 		s_ie[tid] = s_is[tid] + ca.I[pa.child_base + tid];
@@ -566,31 +1037,38 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	const uint32_t nf = nfull[blockIdx.x];
 	const uint32_t nsl = st.slot_hi - st.slot_lo;
 	// ---- count (both passes need the per-workgroup counts)
-	for (uint32_t o = tid; o < ((nsl + 255) & ~255u); o += 256) {
+	uint32_t my_holes = 0;
+	for (uint32_t o = tid; o < nsl; o += 256) {
 		const uint32_t i = st.slot_lo + o;
-		bool hole = false;
-		int own = -1;
-		if (o < nsl) {
-			own = slot_owner(s_is, s_ie, W, i);
-			if (o < nf) {
-				const uint32_t d = block_map[i];
-				if ((int)d != own) atomicAdd(&s_cls[own >= 0 ? 0 : 1][d], 1u);
-			} else
-				hole = own >= 0;
-		}
-		if (!SCATTER) { // holes: one global fetch-add per wave
-			const uint64_t hm = __ballot(hole);
-			if (hm) {
-				const int ldr = __ffsll((long long)hm) - 1;
-				uint32_t base = 0;
-				if ((int)lane == ldr) base = atomicAdd(&ctr->nholes, (uint32_t)__popcll(hm));
-				base = __shfl(base, ldr);
-				if (hole) {
-					ListEntry e;
-					e.slot = i;
-					e.owner = pa.child_base + (uint32_t)own;
-					holes[base + __popcll(hm & ((1ull << lane) - 1ull))] = e;
-				}
+		const int own = slot_owner(s_is, s_ie, W, i);
+		if (slot_full ? slot_full[i] != 0 : o < nf) {
+			const uint32_t d = block_map[i];
+			if ((int)d != own) atomicAdd(&s_cls[own >= 0 ? 0 : 1][d], 1u);
+		} else if (own >= 0)
+			++my_holes;
+	}
+	if (!SCATTER) { // holes: one global fetch-add per workgroup, positions from an LDS cursor
+		__shared__ uint32_t s_hcount, s_hbase;
+		if (tid == 0) s_hcount = 0;
+		__syncthreads();
+		if (my_holes) atomicAdd(&s_hcount, my_holes);
+		__syncthreads();
+		const uint32_t nh = s_hcount;
+		if (nh) { // (uniform)
+			if (tid == 0) {
+				s_hbase = atomicAdd(&ctr->nholes, nh);
+				s_hcount = 0;
+			}
+			__syncthreads();
+			for (uint32_t o = tid; o < nsl; o += 256) {
+				const uint32_t i = st.slot_lo + o;
+				if (slot_full ? slot_full[i] != 0 : o < nf) continue;
+				const int own = slot_owner(s_is, s_ie, W, i);
+				if (own < 0) continue;
+				ListEntry e;
+				e.slot = i;
+				e.owner = pa.child_base + (uint32_t)own;
+				holes[s_hbase + atomicAdd(&s_hcount, 1u)] = e;
 			}
 		}
 	}
@@ -612,8 +1090,9 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 		s_cls[1][tid] = 0;
 	}
 	__syncthreads();
-	for (uint32_t o = tid; o < nf && o < nsl; o += 256) {
+	for (uint32_t o = tid; o < (slot_full ? nsl : (nf < nsl ? nf : nsl)); o += 256) {
 		const uint32_t i = st.slot_lo + o;
+		if (slot_full && !slot_full[i]) continue;
 		const int own = slot_owner(s_is, s_ie, W, i);
 		const uint32_t d = block_map[i];
 		if ((int)d != own) {
@@ -943,102 +1422,149 @@ constexpr uint64_t kCountMedMax = 1ull << 17; // largest segment one workgroup c
 // fall on different LDS banks (unpadded, the stride-16 walk is a 32-way bank conflict)
 constexpr size_t kCountCwBytes = (((size_t)1 << kCountMaxBits) / 4 + ((size_t)1 << kCountMaxBits) / 128 + 4) * 4;
 constexpr int kCountStageBytes = 14080; // output window; with the counters: two workgroups per CU
-constexpr size_t kCountLds = kCountCwBytes + kCountStageBytes + 128;
+constexpr size_t kCountLds = kCountCwBytes + kCountStageBytes + 128; // 128: wave totals, flag, ticket, prefix
 __device__ __forceinline__ uint32_t cw_at(uint32_t i) { return i + (i >> 5); }
 
+// Persistent workgroups: each takes segments by ticket and loads the first 16 keys per thread of
+// its NEXT segment before it re-generates the current one, so the load latency of a segment
+// (the largest part of a 16 Ki-key segment's life) is hidden behind the previous one's work.
 template <typename K>
-__global__ __launch_bounds__(kCountTh) void count_sort_kernel(K *__restrict__ keys,
+__global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__ keys,
 	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ fallback, uint32_t fallback_base,
 	uint32_t lds_cap, Segment *__restrict__ big, uint32_t big_cap, Counters *__restrict__ ctr)
 {
 	constexpr uint32_t WS = kCountStageBytes / sizeof(K); // keys per output window
+	// keys per thread held in registers: a little more than 2^14 / 1024, the typical segment
+	constexpr int kCountPf = sizeof(K) == 4 ? 20 : 8;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);    // packed byte counters (padded layout)
 	K *stage = reinterpret_cast<K *>(smem + kCountCwBytes);
 	uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + kCountCwBytes + kCountStageBytes); // 16 wave totals
-	uint32_t *flag = wtot + 16;
+	uint32_t *nexti = wtot + 17;
+	K *hi_l = reinterpret_cast<K *>(wtot + 18); // 8 bytes
+	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	if (blockIdx.x >= nsegs) return;
-	const Segment sg = segs[blockIdx.x];
-	const uint32_t n = (uint32_t)sg.count, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const uint32_t nv = 1u << sg.bits, mask = nv - 1u;
-	const uint32_t nwords = nv >= 4 ? nv / 4 : 1;
-	K *seg = keys + sg.start;
+	Segment sg = segs[blockIdx.x];
+	K pk[kCountPf];
+	auto prefetch = [&](const Segment &g) {
+		const K *src = keys + g.start;
+		const uint32_t cnt = (uint32_t)g.count;
+#pragma unroll
+		for (int u = 0; u < kCountPf; ++u) { // (uniform base and bound per u: one address register for all loads)
+			const K *srcu = src + u * kCountTh;
+			const uint32_t left = cnt > (uint32_t)(u * kCountTh) ? cnt - u * kCountTh : 0u;
+			pk[u] = tid < left ? srcu[tid] : (K)0;
+		}
+	};
+	prefetch(sg);
+	for (;;) {
+		const uint32_t n = (uint32_t)sg.count;
+		const uint32_t nv = 1u << sg.bits, mask = nv - 1u;
+		const uint32_t nwords = nv >= 4 ? nv / 4 : 1;
+		K *seg = keys + sg.start;
 
-	for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
-	if (tid == 0) *flag = 0;
-	__syncthreads();
-	const K hi = seg[0] & ~(K)mask; // common prefix of the whole segment
-	bool ovf = false;
-	for (uint32_t i0 = 0; i0 < n; i0 += 4 * kCountTh) {
-		K k4[4];
+		for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
+		if (tid == 0) *nexti = atomicAdd(&ctr->count_ticket, 1u) + gridDim.x;
+		__syncthreads();
+		// A byte that overflows carries into its neighbour: the sum of all bytes then falls short of
+		// n (every carry loses 255 or 256), which the prefix sums below notice -- no per-key check.
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t idx = i0 + u * kCountTh + tid;
-			k4[u] = idx < n ? seg[idx] : (K)0;
+		for (int u = 0; u < kCountPf; ++u) {
+			const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+			if (tid < left) {
+				const uint32_t v = (uint32_t)pk[u] & mask;
+				atomicAdd(&cw[cw_at(v >> 2)], 1u << ((v & 3u) * 8u));
+			}
 		}
+		if (tid == 0) *hi_l = pk[0] & ~(K)mask; // common prefix of the whole segment
+		for (uint32_t i0 = kCountPf * kCountTh; i0 < n; i0 += 4 * kCountTh) { // segments above 16 Ki keys
+			K k4[4];
 #pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const uint32_t idx = i0 + u * kCountTh + tid;
-			if (idx < n) {
-				const uint32_t v = (uint32_t)k4[u] & mask, sh = (v & 3u) * 8u;
-				const uint32_t old = atomicAdd(&cw[cw_at(v >> 2)], 1u << sh);
-				ovf |= ((old >> sh) & 0xFFu) == 0xFFu;
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t idx = i0 + u * kCountTh + tid;
+				k4[u] = idx < n ? seg[idx] : (K)0;
 			}
-		}
-	}
-	if (ovf) *flag = 1;
-	__syncthreads();
-	if (*flag) { // some value occurs > 255 times: hand the untouched segment on
-		if (tid == 0) {
-			if (n <= lds_cap) { // ... to the general LDS sort
-				const uint32_t at = atomicAdd(&ctr->nfallback, 1u);
-				fallback[fallback_base + at] = sg;
-			} else {            // ... to the multi-workgroup counting sort (32-bit counters)
-				const uint32_t at = big ? atomicAdd(&ctr->nbig, 1u) : 0xFFFFFFFFu;
-				if (at < big_cap) big[at] = sg; else atomicAdd(&ctr->errors, 1u);
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const uint32_t idx = i0 + u * kCountTh + tid;
+				if (idx < n) {
+					const uint32_t v = (uint32_t)k4[u] & mask;
+					atomicAdd(&cw[cw_at(v >> 2)], 1u << ((v & 3u) * 8u));
+				}
 			}
-		}
-		return;
-	}
-	// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
-	const uint32_t wpt = nwords >= kCountTh ? nwords / kCountTh : 1;
-	const uint32_t w0 = tid * wpt;
-	uint32_t tot = 0;
-	uint64_t nz = 0; // one bit per non-empty byte counter of this thread
-	if (w0 < nwords) {
-		for (uint32_t j = 0; j < wpt; ++j) {
-			const uint32_t x = cw[cw_at(w0 + j)];
-			tot = __builtin_amdgcn_sad_u8(x, 0u, tot); // byte sum
-			const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
-			nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
-		}
-	}
-	const uint32_t inc = wave_incl_scan(tot);
-	if (lane == 63) wtot[w] = inc;
-	__syncthreads();
-	uint32_t pos = inc - tot;
-	for (uint32_t ww = 0; ww < w; ++ww) pos += wtot[ww];
-	const uint32_t end = pos + tot;
-	// ---- re-generate the sorted keys window by window through LDS (coalesced stores).
-	// A thread's keys form one ascending run [pos, end); it resumes where the last window cut it.
-	uint32_t c = 0;
-	K cur = 0;
-	for (uint32_t wbeg = 0; wbeg < n; wbeg += WS) {
-		const uint32_t wend = wbeg + WS < n ? wbeg + WS : n;
-		while (pos < end && pos < wend) {
-			if (c == 0) { // next non-empty counter (one exists because pos < end)
-				const uint32_t i = (uint32_t)__ffsll((long long)nz) - 1u;
-				nz &= nz - 1;
-				c = (cw[cw_at(w0 + (i >> 2))] >> (8u * (i & 3u))) & 0xFFu;
-				cur = hi | (K)((w0 + (i >> 2)) * 4u + (i & 3u));
-			}
-			stage[pos - wbeg] = cur;
-			++pos;
-			--c;
 		}
 		__syncthreads();
-		for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = stage[i];
+		const uint32_t nxt = *nexti;
+		const K hi = *hi_l;
+		Segment nsg = sg;
+		if (nxt < nsegs) { // the next segment's keys travel while this one is written
+			nsg = segs[nxt];
+			prefetch(nsg);
+		}
+		// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
+		// (wpt divides 32, so the owned words are consecutive in the padded layout too)
+		const uint32_t wpt = nwords >= kCountTh ? nwords / kCountTh : 1;
+		const uint32_t w0 = tid * wpt;
+		const uint32_t *cwp = cw + cw_at(w0);
+		uint32_t tot = 0;
+		uint64_t nz = 0; // one bit per non-empty byte counter of this thread
+		if (w0 < nwords) {
+#pragma unroll 4
+			for (uint32_t j = 0; j < wpt; ++j) {
+				const uint32_t x = cwp[j];
+				tot = __builtin_amdgcn_sad_u8(x, 0u, tot); // byte sum
+				const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
+				nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
+			}
+		}
+		const uint32_t inc = wave_incl_scan(tot);
+		if (lane == 63) wtot[w] = inc;
 		__syncthreads();
+		uint32_t pos = inc - tot, all = 0;
+#pragma unroll 2
+		for (uint32_t ww = 0; ww < kCountTh / 64; ++ww) {
+			const uint32_t t = wtot[ww];
+			if (ww < w) pos += t;
+			all += t;
+		}
+		if (all != n) { // some value occurs > 255 times: hand the untouched segment on
+			if (tid == 0) {
+				if (n <= lds_cap) { // ... to the general LDS sort
+					const uint32_t at = atomicAdd(&ctr->nfallback, 1u);
+					fallback[fallback_base + at] = sg;
+				} else {            // ... to the multi-workgroup counting sort (32-bit counters)
+					const uint32_t at = big ? atomicAdd(&ctr->nbig, 1u) : 0xFFFFFFFFu;
+					if (at < big_cap) big[at] = sg; else atomicAdd(&ctr->errors, 1u);
+				}
+			}
+		} else {
+			const uint32_t end = pos + tot;
+			const K hi4 = hi | (K)(w0 * 4u);
+			// ---- re-generate the sorted keys window by window through LDS (coalesced stores).
+			// A thread's keys form one ascending run [pos, end); it resumes where the last window cut it.
+			uint32_t c = 0;
+			K cur = 0;
+			for (uint32_t wbeg = 0; wbeg < n; wbeg += WS) {
+				const uint32_t wend = wbeg + WS < n ? wbeg + WS : n;
+				while (pos < end && pos < wend) {
+					if (c == 0) { // next non-empty counter (one exists because pos < end)
+						const uint32_t i = (uint32_t)__ffsll((long long)nz) - 1u;
+						nz &= nz - 1;
+						c = (cwp[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
+						cur = hi4 + (K)i;
+					}
+					stage[pos - wbeg] = cur;
+					++pos;
+					--c;
+				}
+				__syncthreads();
+				for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = stage[i];
+				__syncthreads();
+			}
+		}
+		if (nxt >= nsegs) break;
+		sg = nsg;
+		__syncthreads(); // nexti / hi_l / wtot are rewritten next
 	}
 }
 

@@ -42,6 +42,10 @@ struct msd_ctx {
 	std::vector<std::pair<std::string, double>> phase_us;
 	std::vector<std::pair<std::string, uint64_t>> stats;
 	int sm_count = 256;
+	// direct block placement in the first round: 0 off, 1 when the sampled
+	// children are about equally big, 2 whenever the geometry allows (tests)
+	int direct_mode = 1;
+	uint64_t direct_min = 1ull << 26; // smallest parent it is tried on
 };
 
 static int fail(msd_ctx *c, int code, const char *fmt, ...)
@@ -270,7 +274,7 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 			st.lo_base = rp.lo_elems;
 			st.pad = 0;
 			// leftovers: < B per bucket (2^width buckets) from the stream, plus < B head keys
-			rp.lo_elems += std::min<uint64_t>(e - b, ((uint64_t)1 << p.width) * (B - 1) + B);
+			rp.lo_elems += std::min<uint64_t>(e - b, ((uint64_t)1 << p.width) * (B - 1) + 2 * B);
 			rp.nslots += st.slot_hi - st.slot_lo;
 			rp.stripes.push_back(st);
 			b = e;
@@ -364,6 +368,8 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 {
 	Bump b(nullptr);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
+	b.take<uint8_t>(n / Cfg<K, V>::B + 2); // slot_full (direct placement)
+	b.take<DirectPlan>(1);
 	b.take<Counters>(2); // counters + scratch for the varying-bit reduction
 	b.take<Segment>(n / ((uint64_t)Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT) + 16); // big counting-sort segments
 	return b.off + 4096;
@@ -431,6 +437,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 	Bump kb(c->keep);
 	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
+	uint8_t *slot_full = kb.take<uint8_t>(n / B + 2);
+	DirectPlan *dplan = kb.take<DirectPlan>(1);
 	Counters *ctr = kb.take<Counters>(2);
 	const uint32_t big_cap = (uint32_t)std::min<uint64_t>(n / small_max + 16, 0x7FFFFFFFu);
 	Segment *big = kb.take<Segment>(big_cap);
@@ -535,24 +543,59 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		phase_mark(c, "plan+upload");
 
 		// ---- A: classify (histogram falls out of it)
-		constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
-		hipLaunchKernelGGL((classify_kernel<K, V>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
-				   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
-				   (K *)rb.lo_keys, rb.lo_vals, rb.nfull);
-		HIPCHK(c, hipGetLastError());
+		bool direct = false;
+		// (tuples: measured slower than stripe-local classification + full permutation, so only when forced)
+		if ((HV ? c->direct_mode == 2 : c->direct_mode != 0) && !single_pass && np == 1 && rp.parents[0].count >= c->direct_min) {
+			// direct placement: sampled child boundaries; worth it only for about equally big children
+			HIPCHK(c, hipMemsetAsync(dplan, 0, sizeof(DirectPlan), c->stream));
+			// sample about 2^22 keys or more, as runs of 256 spread evenly over the parent
+			const uint64_t nruns = rp.parents[0].count / 256;
+			const uint32_t every = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, nruns / 16384));
+			const uint32_t sgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, nruns / every / 4));
+			hipLaunchKernelGGL((direct_sample_kernel<K>), dim3(sgrid), dim3(256), 0, c->stream, (const K *)keys, rb.parents, dplan, every);
+			HIPCHK(c, hipMemcpyAsync(c->pinned, dplan, sizeof(uint32_t) * kP, hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+			const uint32_t *ec = (const uint32_t *)c->pinned;
+			uint32_t mn = ~0u, mx = 0;
+			for (int d = 0; d < (1 << rp.parents[0].width); ++d) {
+				mn = std::min(mn, ec[d]);
+				mx = std::max(mx, ec[d]);
+			}
+			// a piece is at most one stripe's share of the parent's slots; the kernel counts it in 16 bits
+			const uint64_t max_piece = rp.parents[0].count / B / ns + 2;
+			const bool even = mn > 0 && (double)mx <= 1.25 * (double)mn;
+			direct = (even || c->direct_mode == 2) && max_piece < 65535;
+			if (direct) {
+				hipLaunchKernelGGL((direct_plan_kernel<B>), dim3(1), dim3(256), 0, c->stream, rb.parents, dplan);
+				constexpr size_t direct_lds = DirectLds<K, V>::bytes;
+				hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
+						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)dplan, block_map, slot_full,
+						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
+				HIPCHK(c, hipGetLastError());
+				add_stat(c, "direct_rounds", 1);
+			}
+		}
+		if (!direct) {
+			constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
+			hipLaunchKernelGGL((classify_kernel<K, V>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
+					   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+					   (K *)rb.lo_keys, rb.lo_vals, rb.nfull);
+			HIPCHK(c, hipGetLastError());
+		}
+		const uint8_t *full_map = direct ? (const uint8_t *)slot_full : (const uint8_t *)nullptr;
 		phase_mark(c, "A classify");
 
 		// ---- block metadata: child geometry, misplaced-block lists, holes
 		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(1024), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
 		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
-				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr);
+				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
 		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca);
 		{
 			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors);
 			if (rc) return rc;
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
-				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr);
+				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
 		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
 				   keys, vals, (K *)rb.xkeys, rb.xvals);
 		HIPCHK(c, hipGetLastError());
@@ -615,7 +658,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	constexpr size_t sort_lds = SortLds<K, V>::bytes;
 	if constexpr (!HV) {
 		if (ncount_host && !single_pass) {
-			hipLaunchKernelGGL((count_sort_kernel<K>), dim3(ncount_host), dim3(kCountTh), kCountLds, c->stream,
+			// persistent workgroups (two per CU fit the LDS), segments handed out by ticket
+			const uint32_t count_grid = std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count * 2);
+			hipLaunchKernelGGL((count_sort_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
 					   keys, small_count, ncount_host, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
 			HIPCHK(c, hipGetLastError());
 			phase_mark(c, "count sort");
@@ -719,6 +764,8 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct_kernel<K, V>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DirectLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
@@ -754,6 +801,7 @@ int msd_create(msd_ctx **out, int device, void *stream)
 	}
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->sm_count = prop.multiProcessorCount;
+	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switch for benchmarks
 	int rc = set_lds_attrs<uint32_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, uint64_t>(c);
@@ -1007,6 +1055,20 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
 	if (key_bytes == 8 && val_bytes == 0) return plan_describe<uint64_t, NoVal>(n, end_bit, cus, out);
 	if (key_bytes == 8 && val_bytes == 8) return plan_describe<uint64_t, uint64_t>(n, end_bit, cus, out);
 	return MSD_EINVAL;
+}
+
+int msd_set_option(msd_ctx *c, const char *name, int64_t value)
+{
+	if (!c || !name) return MSD_EINVAL;
+	if (!strcmp(name, "direct_mode")) {
+		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "direct_mode must be 0, 1 or 2");
+		c->direct_mode = (int)value;
+	} else if (!strcmp(name, "direct_min")) {
+		if (value < 1) return fail(c, MSD_EINVAL, "direct_min must be positive");
+		c->direct_min = (uint64_t)value;
+	} else
+		return fail(c, MSD_EINVAL, "unknown option %s", name);
+	return MSD_OK;
 }
 
 int msd_set_profiling(msd_ctx *c, int on)

@@ -1,0 +1,138 @@
+"""GPU parity of the first round's direct block placement.
+
+By default the path is only tried on inputs of 2^26 elements and more whose sampled top-digit
+buckets are about equally big; here `direct_min` is lowered so that it runs at sizes numpy
+sorts in a moment, and `direct_mode` 2 drops the sample test so that it also meets inputs it
+is not meant for (skew, few distinct values, sorted runs) -- slow there, but still exact.
+The reference has no counterpart; the oracle is numpy's sort of the same keys (bit-exact).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int32 if a.dtype == np.uint32 else np.int64)).cuda()
+
+
+def host(t):
+    a = t.cpu().numpy()
+    return a.view(np.uint32) if a.dtype == np.int32 else a.view(np.uint64)
+
+
+@pytest.fixture()
+def dctx(ctx):
+    ctx.set_option("direct_min", 1 << 16)
+    ctx.set_option("direct_mode", 1)
+    yield ctx
+    ctx.set_option("direct_min", 1 << 26)
+    ctx.set_option("direct_mode", 1)
+
+
+def shapes(rng, n, kind, bits):
+    full = (1 << bits) - 1
+    dt = np.uint32 if bits == 32 else np.uint64
+    if kind == "uniform":
+        k = rng.integers(0, full, n, dtype=np.uint64, endpoint=True)
+    elif kind == "sorted":
+        k = np.sort(rng.integers(0, full, n, dtype=np.uint64, endpoint=True))
+    elif kind == "reversed":
+        k = np.sort(rng.integers(0, full, n, dtype=np.uint64, endpoint=True))[::-1].copy()
+    elif kind == "stride":      # top digit cycles with the position: every stripe sees one bucket at a time
+        k = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15 & full)) & np.uint64(full)
+    elif kind == "runs":        # long runs of one top digit each (a piece is read long before it can be written)
+        top = (np.arange(n, dtype=np.uint64) // np.uint64(4096)) % np.uint64(256)
+        k = (top << np.uint64(bits - 8)) | rng.integers(0, (1 << (bits - 8)) - 1, n, dtype=np.uint64)
+    elif kind == "lowbits":     # uniform top digit, everything below it constant
+        k = rng.integers(0, 255, n, dtype=np.uint64, endpoint=True) << np.uint64(bits - 8)
+    elif kind == "zipf":
+        k = O.gen_zipf_u32(n, seed=int(rng.integers(1, 1 << 30))).astype(np.uint64)
+        if bits == 64:
+            k = k << np.uint64(32) | k
+    elif kind == "heavy":       # one value takes a third of the input
+        k = rng.integers(0, full, n, dtype=np.uint64, endpoint=True)
+        k[rng.random(n) < 0.33] = np.uint64(0x5A5A5A5A5A5A5A5A & full)
+    else:
+        raise ValueError(kind)
+    return (k & np.uint64(full)).astype(dt)
+
+
+KINDS_EVEN = ["uniform", "sorted", "reversed", "stride", "runs", "lowbits"]
+
+
+@pytest.mark.parametrize("kind", KINDS_EVEN)
+@pytest.mark.parametrize("logn", [20, 22, 23])
+def test_direct_u32_even_buckets(dctx, kind, logn):
+    rng = np.random.default_rng(logn * 100 + len(kind))
+    n = (1 << logn) + int(rng.integers(0, 200))
+    k = shapes(rng, n, kind, 32)
+    t = dev(k)
+    dctx.sort_u32(t)
+    assert (host(t) == np.sort(k)).all()
+    if kind in ("uniform", "stride"):  # the others may need no 8-bit round at all (few varying bits)
+        assert dctx.stats().get("direct_rounds", 0) == 1, "the direct path did not run"
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf", "heavy", "runs", "sorted"])
+@pytest.mark.parametrize("typ", ["u32", "u64", "pairs"])
+def test_direct_forced_any_distribution(dctx, kind, typ):
+    dctx.set_option("direct_mode", 2)
+    rng = np.random.default_rng(7 + len(kind) * 13 + len(typ))
+    n = (1 << 21) + int(rng.integers(1, 77))
+    k = shapes(rng, n, kind, 32 if typ == "u32" else 64)
+    t = dev(k)
+    if typ == "u32":
+        dctx.sort_u32(t)
+        assert (host(t) == np.sort(k)).all()
+    elif typ == "u64":
+        dctx.sort_u64(t)
+        assert (host(t) == np.sort(k)).all()
+    else:
+        r = np.arange(n, dtype=np.uint64)
+        tr = dev(r)
+        dctx.sort_pairs_u64(t, tr)
+        ko, ro = host(t), host(tr)
+        assert (ko == np.sort(k)).all()
+        assert (k[ro] == ko).all() and (np.sort(ro) == r).all()
+
+
+def test_direct_unaligned_start_and_odd_length(dctx):
+    rng = np.random.default_rng(99)
+    for off, n in [(4, (1 << 20) + 1), (8, (1 << 20) - 63), (12, (1 << 18) + 64)]:
+        k = shapes(rng, n + off, "uniform", 32)
+        t = dev(k)
+        dctx.sort_u32(t[off:])
+        out = host(t)
+        assert (out[:off] == k[:off]).all() and (out[off:] == np.sort(k[off:])).all()
+
+
+def test_direct_repeated_runs_identical(dctx):
+    rng = np.random.default_rng(5)
+    k = shapes(rng, (1 << 22) + 3, "uniform", 32)
+    exp = np.sort(k)
+    for _ in range(4):
+        t = dev(k)
+        dctx.sort_u32(t)
+        assert (host(t) == exp).all()
+
+
+def test_direct_off_matches(dctx):
+    rng = np.random.default_rng(6)
+    k = shapes(rng, 1 << 21, "uniform", 32)
+    dctx.set_option("direct_mode", 0)
+    t = dev(k)
+    dctx.sort_u32(t)
+    assert dctx.stats().get("direct_rounds", 0) == 0
+    assert (host(t) == np.sort(k)).all()
+
+
+def test_set_option_rejects_unknown(ctx):
+    with pytest.raises(Exception):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(Exception):
+        ctx.set_option("direct_mode", 7)

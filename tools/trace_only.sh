@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: tools/trace_only.sh <tag> <logn> [kind]  -- kernel-trace stats only, under gpurun_out/<tag>/
+set -e
+TAG=$1; LOGN=${2:-28}; KIND=${3:-uniform}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/tools/prof_run.py $LOGN 3 $KIND > $OUT/trace.log 2>&1
+S=$(find $OUT/trace -name "*kernel_stats.csv" | head -n 1)
+python3 - "$S" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:24]:
+    print(f"{r['Name'][:70]:70s} calls={r['Calls']:>5s} avg_us={float(r['AverageNs'])/1e3:9.1f} tot_ms={float(r['TotalDurationNs'])/1e6:8.2f} {r['Percentage']}%")
+PY
