@@ -1435,7 +1435,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 {
 	constexpr uint32_t WS = kCountStageBytes / sizeof(K); // keys per output window
 	// keys per thread held in registers: a little more than 2^14 / 1024, the typical segment
-	constexpr int kCountPf = sizeof(K) == 4 ? 20 : 8;
+	constexpr int kCountPf = sizeof(K) == 4 ? 17 : 9;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);    // packed byte counters (padded layout)
 	K *stage = reinterpret_cast<K *>(smem + kCountCwBytes);
@@ -1450,10 +1450,9 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 		const K *src = keys + g.start;
 		const uint32_t cnt = (uint32_t)g.count;
 #pragma unroll
-		for (int u = 0; u < kCountPf; ++u) { // (uniform base and bound per u: one address register for all loads)
-			const K *srcu = src + u * kCountTh;
-			const uint32_t left = cnt > (uint32_t)(u * kCountTh) ? cnt - u * kCountTh : 0u;
-			pk[u] = tid < left ? srcu[tid] : (K)0;
+		for (int u = 0; u < kCountPf; ++u) { // branch-free: out-of-range lanes re-read the last key (ignored when counting)
+			const uint32_t idx = min((uint32_t)(u * kCountTh) + tid, cnt - 1u);
+			pk[u] = src[idx];
 		}
 	};
 	prefetch(sg);
@@ -1497,10 +1496,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 		const uint32_t nxt = *nexti;
 		const K hi = *hi_l;
 		Segment nsg = sg;
-		if (nxt < nsegs) { // the next segment's keys travel while this one is written
-			nsg = segs[nxt];
-			prefetch(nsg);
-		}
+		bool fetched = false;
 		// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
 		// (wpt divides 32, so the owned words are consecutive in the padded layout too)
 		const uint32_t wpt = nwords >= kCountTh ? nwords / kCountTh : 1;
@@ -1544,7 +1540,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 			// A thread's keys form one ascending run [pos, end); it resumes where the last window cut it.
 			uint32_t c = 0;
 			K cur = 0;
-			for (uint32_t wbeg = 0; wbeg < n; wbeg += WS) {
+			auto window = [&](uint32_t wbeg) {
 				const uint32_t wend = wbeg + WS < n ? wbeg + WS : n;
 				while (pos < end && pos < wend) {
 					if (c == 0) { // next non-empty counter (one exists because pos < end)
@@ -1560,7 +1556,21 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 				__syncthreads();
 				for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = stage[i];
 				__syncthreads();
+			};
+			uint32_t wbeg = 0;
+			for (; wbeg + WS < n; wbeg += WS) window(wbeg);
+			// the next segment's first keys travel while the last window is written (their registers
+			// are free only now, and are needed again right after the counters are cleared)
+			if (nxt < nsegs) {
+				nsg = segs[nxt];
+				prefetch(nsg);
+				fetched = true;
 			}
+			window(wbeg);
+		}
+		if (!fetched && nxt < nsegs) {
+			nsg = segs[nxt];
+			prefetch(nsg);
 		}
 		if (nxt >= nsegs) break;
 		sg = nsg;
