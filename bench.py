@@ -33,6 +33,7 @@ BYTES_PER_KEY_PASS = 12
 # (each really moves 4 B in + 4 B out per key), and digit passes done per launch
 KERNEL_ALGO = {
     "A classify": ("classify_kernel<u32>", 6.0),       # per key per round
+    "A classify direct": ("classify_direct_kernel<u32>", 6.0),  # first round, blocks placed directly (one launch)
     "B block permute": ("chains_kernel<u32>", 6.0),    # per key per round
     "LDS sort": ("lds_sort_kernel<u32>", None),        # remaining passes x 12 B per key
     "count sort": ("count_sort_kernel<u32>", None),    # remaining passes x 12 B per key
@@ -204,7 +205,9 @@ def main():
                 passes_left = max(0, 4 - rounds) if args.dist == "uniform" else 2
                 launches, algo = 1, n * BYTES_PER_KEY_PASS * passes_left
             else:
-                launches, algo = max(1, rounds), n * per_key
+                direct = st.get("direct_rounds", 0)
+                launches = 1 if dom == "A classify direct" else max(1, rounds - (direct if dom == "A classify" else 0))
+                algo = n * per_key
             avg_us = ph[dom] / launches
             ach = algo / (avg_us * 1e-6) / 1e9
             traffic = None
@@ -216,6 +219,7 @@ def main():
                     traffic = None
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "moved_GBps": None if not traffic else round(traffic / (avg_us * 1e-6) / 1e9, 1),
                         "avg_launch_us": round(avg_us, 1), "launches_per_sort": launches,
                         "algorithmic_bytes_per_launch": int(algo),
                         "phases_us": {k: round(v, 1) for k, v in ph.items()}}

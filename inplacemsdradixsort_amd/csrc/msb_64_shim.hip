@@ -112,7 +112,9 @@ void sort(uint64_t **keys, uint64_t **rids, uint64_t *size, int threads, int num
 		if (rc != MSD_OK) die("sort(): device sort failed", msd_last_error(ctx));
 		for (int i = 0; i < msd_phase_count(ctx); ++i)
 			for (int j = 1; j <= 7; ++j)
-				if (!strcmp(msd_phase_name(ctx, i), kPhaseOf[j])) tm[j] += (uint64_t)msd_phase_us(ctx, i);
+				if (!strcmp(msd_phase_name(ctx, i), kPhaseOf[j]) ||
+				    (j == 2 && !strncmp(msd_phase_name(ctx, i), "A ", 2))) // sampling / direct placement count as classify
+					tm[j] += (uint64_t)msd_phase_us(ctx, i);
 		msd_set_profiling(ctx, 0);
 		t0 = now_us();
 		off = 0;

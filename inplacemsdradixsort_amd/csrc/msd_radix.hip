@@ -555,6 +555,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			hipLaunchKernelGGL((direct_sample_kernel<K>), dim3(sgrid), dim3(256), 0, c->stream, (const K *)keys, rb.parents, dplan, every);
 			HIPCHK(c, hipMemcpyAsync(c->pinned, dplan, sizeof(uint32_t) * kP, hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream));
+			phase_mark(c, "A sample");
 			const uint32_t *ec = (const uint32_t *)c->pinned;
 			uint32_t mn = ~0u, mx = 0;
 			for (int d = 0; d < (1 << rp.parents[0].width); ++d) {
@@ -573,6 +574,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
 				HIPCHK(c, hipGetLastError());
 				add_stat(c, "direct_rounds", 1);
+				phase_mark(c, "A classify direct");
 			}
 		}
 		if (!direct) {
