@@ -1442,6 +1442,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 	uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + kCountCwBytes + kCountStageBytes); // 16 wave totals
 	uint32_t *nexti = wtot + 17;
 	K *hi_l = reinterpret_cast<K *>(wtot + 18); // 8 bytes
+	uint32_t *tfree = wtot + 20;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	if (blockIdx.x >= nsegs) return;
 	Segment sg = segs[blockIdx.x];
@@ -1538,10 +1539,15 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 			const K hi4 = hi | (K)(w0 * 4u);
 			// ---- re-generate the sorted keys window by window through LDS (coalesced stores).
 			// A thread's keys form one ascending run [pos, end); it resumes where the last window cut it.
+			// Only the few waves whose runs fall into a window work on it, so the number of windows is
+			// what this phase costs: besides the stage a window also uses the counter words of the
+			// threads that are already done (everything below the first unfinished thread's words), so
+			// the windows grow -- 3 instead of 5 for a 16 Ki-key segment.
 			uint32_t c = 0;
 			K cur = 0;
-			auto window = [&](uint32_t wbeg) {
-				const uint32_t wend = wbeg + WS < n ? wbeg + WS : n;
+			K *cwk = reinterpret_cast<K *>(cw);
+			auto window = [&](uint32_t wbeg, uint32_t wend) -> uint32_t {
+				if (pos <= wend && wend < end) *tfree = tid; // the thread cut by this window's end
 				while (pos < end && pos < wend) {
 					if (c == 0) { // next non-empty counter (one exists because pos < end)
 						const uint32_t i = (uint32_t)__ffsll((long long)nz) - 1u;
@@ -1549,16 +1555,23 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 						c = (cwp[i >> 2] >> (8u * (i & 3u))) & 0xFFu;
 						cur = hi4 + (K)i;
 					}
-					stage[pos - wbeg] = cur;
+					const uint32_t r = pos - wbeg;
+					if (r < WS) stage[r]= cur; else cwk[r - WS] = cur;
 					++pos;
 					--c;
 				}
 				__syncthreads();
-				for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = stage[i];
+				const uint32_t tf = *tfree;
+				for (uint32_t i = tid; i < wend - wbeg; i += kCountTh) seg[wbeg + i] = i < WS ? stage[i] : cwk[i - WS];
 				__syncthreads();
+				return (uint32_t)(cw_at(tf * wpt) * 4u / sizeof(K)); // keys that fit below thread tf's counters
 			};
-			uint32_t wbeg = 0;
-			for (; wbeg + WS < n; wbeg += WS) window(wbeg);
+			uint32_t wbeg = 0, wend = WS < n ? WS : n;
+			while (wend < n) {
+				const uint32_t room = window(wbeg, wend);
+				wbeg = wend;
+				wend = wbeg + WS + room < n ? wbeg + WS + room : n;
+			}
 			// the next segment's first keys travel while the last window is written (their registers
 			// are free only now, and are needed again right after the counters are cleared)
 			if (nxt < nsegs) {
@@ -1566,7 +1579,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 				prefetch(nsg);
 				fetched = true;
 			}
-			window(wbeg);
+			window(wbeg, wend);
 		}
 		if (!fetched && nxt < nsegs) {
 			nsg = segs[nxt];
