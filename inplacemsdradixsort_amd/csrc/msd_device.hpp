@@ -129,6 +129,20 @@ __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v)
 // Exclusive scan over the first 256 threads' values; every thread of the block
 // must call it (it contains barriers).  tmp: >= 5 uint32 of LDS.  Returns the
 // exclusive prefix for threads < 256 and the grand total in `total`.
+// popcount of the bits of `m` below this lane / this lane's bit of `m`, without a lane mask
+// (a hoisted 64-bit (1 << lane) - 1 costs two registers for the whole kernel, and a spill that is
+// reloaded behind an outstanding prefetch stalls on vmcnt)
+__device__ __forceinline__ uint32_t popc_below_lane(uint64_t m)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ bool lane_bit(uint64_t m)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t half = lane < 32u ? (uint32_t)m : (uint32_t)(m >> 32);
+	return (half >> (lane & 31u)) & 1u;
+}
+
 __device__ __forceinline__ uint32_t block_excl_scan256(uint32_t v, uint32_t *tmp, uint32_t &total)
 {
 	const uint32_t tid = threadIdx.x;
@@ -308,7 +322,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 					uint32_t base = 0;
 					if (lane_id() == 0) base = atomicAdd(&cnt[d0], (uint32_t)__popcll(same));
 					base = __builtin_amdgcn_readfirstlane(base);
-					r = d == d0 ? base + (uint32_t)__popcll(same & ((1ull << lane_id()) - 1ull)) : atomicAdd(&cnt[d], 1u);
+					r = d == d0 ? base + popc_below_lane(same) : atomicAdd(&cnt[d], 1u);
 				} else
 					r = atomicAdd(&cnt[d], 1u);
 				dr[i] = d | (r << 8);
@@ -541,13 +555,12 @@ __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int 
 			}
 		}
 		// the candidates left are equal: the lowest `need` lanes of them
-		const uint32_t lane = threadIdx.x & 63;
-		const bool mine = ((cand >> lane) & 1ull) && __popcll(cand & ((1ull << lane) - 1ull)) < need;
+		const bool mine = lane_bit(cand) && (int)popc_below_lane(cand) < need;
 		selm |= __ballot(mine);
 	} else
 		selm = cand;
 	mask_out = selm;
-	return (selm >> (threadIdx.x & 63)) & 1ull;
+	return lane_bit(selm);
 }
 
 template <typename K, typename V>
@@ -657,28 +670,24 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 	};
 	// Which slots to read next: the pieces whose buckets have the least room (read-ahead slots plus
 	// free buffer space) go first, so that a bucket's next slot has been read before its buffer fills.
-	uint32_t rot_r = 0;
-	(void)rot_r;
 	auto select_reads = [&](uint32_t wr, uint32_t rd, uint32_t q, uint32_t fill, uint32_t *count_out) {
 		const bool elig = rd < pnl[tid];
 		const uint32_t v = min(1023u, (rd - wr) * B + B - fill);
 		uint64_t sm;
-#ifdef MSD_EXP_RR
-		(void)v;
-		const uint32_t rot = (rot_r++ & 3u) * SPW; // experiment: plain rotation, no selection
-		sm = __ballot(elig && ((lane - rot) & 63u) < (uint32_t)SPW);
-		const bool mine = (sm >> lane) & 1ull;
-#else
 		const bool mine = wave_select_smallest(v, elig, SPW, sm);
-#endif
-		const uint32_t n = (uint32_t)__popcll(sm), w = tid >> 6;
+		// the wave's slice of sel[]: a scalar (wave-uniform) base, so that no per-lane address is kept
+		// in a register across the tile loop (the compiler spills such invariants, and a reload behind
+		// the outstanding prefetch waits for it)
+		const uint32_t n = (uint32_t)__popcll(sm);
+		uint32_t *selw = sel + __builtin_amdgcn_readfirstlane(tid >> 6) * SPW;
 		if (mine) {
-			sel[w * SPW + __popcll(sm & ((1ull << lane) - 1ull))] = phys(tid, rd);
+			selw[popc_below_lane(sm)] = phys(tid, rd);
 			++rd;
 			q |= 2; // bit0: has a slot in the next tile, bit1: in the tile after it
 		}
-		if (lane < (uint32_t)SPW && lane >= n) sel[w * SPW + lane] = NONE;
-		if (lane == 0 && n) atomicAdd(count_out, n);
+		const uint32_t l = popc_below_lane(~0ull); // = lane id
+		if (l < (uint32_t)SPW && l >= n) selw[l] = NONE;
+		if (l == 0 && n) atomicAdd(count_out, n);
 		bst[tid] = rd | (q << 16) | (fill << 18);
 	};
 	auto load_tile = [&](K *kr, uint64_t *vr) -> bool {
@@ -798,7 +807,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 				} else {
 					const uint32_t x = atomicAdd(&tmp[2 + par], 1u);
 					if (x < (uint32_t)L::XT) {
-						xtab[2 * x] = (tid << 16) | bi;
+						uint32_t tq = tid;
+						asm volatile("" : "+v"(tq)); // keep (tid << 16) out of the loop-invariant registers
+						xtab[2 * x] = (tq << 16) | bi;
 						xtab[2 * x + 1] = slot;
 						block_map[slot] = (uint8_t)tid;
 					} else
