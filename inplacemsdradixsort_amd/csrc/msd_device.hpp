@@ -263,28 +263,33 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 #pragma unroll
 	for (int i = 0; i < KPT; ++i) dat[i] = 0xFFFFFFFFu;
 
+	// (uniform 64-bit base + 32-bit per-thread offset: a per-thread 64-bit index would be kept in two
+	// registers across the tile loop, spilled, and its reload would wait for the prefetch in flight)
 	auto load_tile = [&](uint64_t pos, K *kr, uint64_t *vr) {
+		const K *kp = keys + pos;
+		const uint64_t *vp = vals + pos;
+		const uint32_t rem = pos < st.end ? (uint32_t)(st.end - pos < (uint64_t)T ? st.end - pos : (uint64_t)T) : 0u;
 #pragma unroll
 		for (int v = 0; v < NV; ++v) {
-			const uint64_t idx = pos + (uint64_t)(v * TH + tid) * VEC;
-			if (idx + VEC <= st.end) {
+			const uint32_t off = (uint32_t)(v * TH + tid) * VEC;
+			if (off + VEC <= rem) {
 				if constexpr (sizeof(K) == 4) {
-					const uint4 q = *reinterpret_cast<const uint4 *>(keys + idx);
+					const uint4 q = *reinterpret_cast<const uint4 *>(kp + off);
 					kr[v * VEC + 0] = q.x; kr[v * VEC + 1] = q.y; kr[v * VEC + 2] = q.z; kr[v * VEC + 3] = q.w;
 				} else {
-					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + idx);
+					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(kp + off);
 					kr[v * VEC + 0] = q.x; kr[v * VEC + 1] = q.y;
 				}
 				if constexpr (HV) {
-					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + idx);
+					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vp + off);
 					vr[v * VEC + 0] = q.x; vr[v * VEC + 1] = q.y;
 				}
 			} else {
 #pragma unroll
 				for (int e = 0; e < VEC; ++e) {
-					if (idx + e < st.end) {
-						kr[v * VEC + e] = keys[idx + e];
-						if constexpr (HV) vr[v * VEC + e] = vals[idx + e];
+					if (off + e < rem) {
+						kr[v * VEC + e] = kp[off + e];
+						if constexpr (HV) vr[v * VEC + e] = vp[off + e];
 					}
 				}
 			}
@@ -334,11 +339,12 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 				dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
 			}
 		} else {
+			const uint32_t rem = (uint32_t)(st.end - pos); // < T here (partial last tile)
 #pragma unroll
 			for (int i = 0; i < KPT; ++i) {
-				const uint64_t idx = pos + (uint64_t)((i / VEC) * TH + tid) * VEC + (i % VEC);
+				const uint32_t off = (uint32_t)((i / VEC) * TH + tid) * VEC + (i % VEC);
 				dr[i] = 0xFFFFFFFFu;
-				if (idx < st.end) {
+				if (off < rem) {
 					const uint32_t d = digit_of(kc[i], shift, mask);
 					dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
 				}
