@@ -33,7 +33,10 @@ BYTES_PER_KEY_PASS = 12
 # (each really moves 4 B in + 4 B out per key), and digit passes done per launch
 KERNEL_ALGO = {
     "A classify": ("classify_kernel<u32>", 6.0),       # per key per round
-    "A classify direct": ("classify_direct_kernel<u32>", 6.0),  # first round, blocks placed directly (one launch)
+    # direct rounds: the permute read + write of the round's 12 B (the histogram read is the sample / the
+    # exact counting pass, "A histogram"); the few misplaced blocks chains still moves are not credited
+    "A classify direct": ("classify_direct_kernel<u32>", 8.0),
+    "A histogram": ("direct_hist_kernel<u32>", 4.0),
     "B block permute": ("chains_kernel<u32>", 6.0),    # per key per round
     "LDS sort": ("lds_sort_kernel<u32>", None),        # remaining passes x 12 B per key
     "count sort": ("count_sort_kernel<u32>", None),    # remaining passes x 12 B per key
@@ -206,7 +209,14 @@ def main():
                 launches, algo = 1, n * BYTES_PER_KEY_PASS * passes_left
             else:
                 direct = st.get("direct_rounds", 0)
-                launches = 1 if dom == "A classify direct" else max(1, rounds - (direct if dom == "A classify" else 0))
+                if dom == "A classify direct":
+                    launches = max(1, direct)
+                elif dom == "A histogram":
+                    launches = max(1, direct - 1)
+                elif dom == "A classify":
+                    launches = max(1, rounds - direct)
+                else:
+                    launches = max(1, rounds)
                 algo = n * per_key
             avg_us = ph[dom] / launches
             ach = algo / (avg_us * 1e-6) / 1e9

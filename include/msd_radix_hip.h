@@ -133,7 +133,9 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  *   all blocks afterwards; 1 (default) = the first round of a large input whose sampled
  *   top-digit buckets are about equally big writes its blocks straight into the bucket's
  *   estimated region and permutes only the misplaced ones; 2 = the same without the sample test.
- * "direct_min": smallest input (elements) direct placement is tried on (default 2^26). */
+ *   Rounds after the first follow (from exact per-parent digit counts) if the first round did.
+ * "direct_min": smallest round (elements) direct placement is tried on (default 2^26).
+ * "direct_min_parent": rounds after the first: smallest parent segment (default 2^17). */
 int msd_set_option(msd_ctx *ctx, const char *name, int64_t value);
 
 /* ---- phase report (reference: description[]/times[], src/msb_64.c:2402-2412) */

@@ -94,7 +94,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t nfallback;    // counting-sort segments handed to the general LDS sort (byte counter overflow)
 	uint32_t nbig;         // cumulative: segments of any size with <= 16 bits left (multi-workgroup counting sort)
 	uint32_t count_ticket; // work ticket of the persistent counting-sort workgroups
-	uint32_t pad[2];
+	uint32_t direct_uneven; // per round: parents whose children are too unequal for direct placement
+	uint32_t pad[1];
 };
 
 // ---------------------------------------------------------------- utilities
@@ -513,12 +514,70 @@ __global__ __launch_bounds__(256) void direct_sample_kernel(const K *__restrict_
 	if (h[threadIdx.x]) atomicAdd(&plan->est_cnt[threadIdx.x], h[threadIdx.x]);
 }
 
+// Exact digit counts per parent for the rounds after the first (a sample will not do there: the
+// error of a sampled boundary is a random walk over the children before it and soon reaches the
+// size of a whole child).  One workgroup per stripe, 16-byte loads, counts in LDS, then one
+// device-scope add per non-empty digit.  A read-only pass: 4 B per u32 key.
+template <typename K>
+__global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__ keys, const Stripe *__restrict__ stripes,
+	const Parent *__restrict__ parents, DirectPlan *__restrict__ plans)
+{
+	constexpr int VEC = Vec16<K>::N;
+	__shared__ uint32_t h[kP];
+	const Stripe st = stripes[blockIdx.x];
+	const Parent pa = parents[st.parent];
+	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u, tid = threadIdx.x;
+	if (tid < kP) h[tid] = 0;
+	__syncthreads();
+	const uint64_t a0 = (st.begin + VEC - 1) / VEC * VEC, a1 = st.end / VEC * VEC; // 16-byte aligned part
+	if (a0 < a1) {
+		for (uint64_t i = st.begin + tid; i < a0; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+		const uint64_t nvec = (a1 - a0) / VEC;
+		for (uint64_t v = tid; v < nvec; v += 4 * 1024) {
+			K kk[4][VEC];
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				const uint64_t vv = v + (uint64_t)u * 1024;
+				if (vv < nvec) {
+					if constexpr (sizeof(K) == 4) {
+						const uint4 q = *reinterpret_cast<const uint4 *>(keys + a0 + vv * VEC);
+						kk[u][0] = q.x; kk[u][1] = q.y; kk[u][2] = q.z; kk[u][3] = q.w;
+					} else {
+						const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + a0 + vv * VEC);
+						kk[u][0] = q.x; kk[u][1] = q.y;
+					}
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < 4; ++u) {
+				if (v + (uint64_t)u * 1024 < nvec) {
+#pragma unroll
+					for (int e = 0; e < VEC; ++e) atomicAdd(&h[digit_of(kk[u][e], shift, mask)], 1u);
+				}
+			}
+		}
+		for (uint64_t i = a1 + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+	} else
+		for (uint64_t i = st.begin + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+	__syncthreads();
+	if (tid < kP && h[tid]) atomicAdd(&plans[st.parent].est_cnt[tid], h[tid]);
+}
+
+// One workgroup per parent: counts (sampled or exact) -> child boundaries on the slot grid; a parent
+// whose biggest child has more than 1.25 x the keys of its smallest one is reported as uneven.
 template <int B>
-__global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restrict__ parents, DirectPlan *__restrict__ plan)
+__global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restrict__ parents, DirectPlan *__restrict__ plans,
+	Counters *__restrict__ ctr)
 {
 	__shared__ uint64_t tmp[8];
-	const Parent pa = parents[0];
+	__shared__ uint32_t s_mn, s_mx;
+	const Parent pa = parents[blockIdx.x];
+	DirectPlan *plan = plans + blockIdx.x;
 	const uint32_t d = threadIdx.x;
+	if (d == 0) {
+		s_mn = 0xFFFFFFFFu;
+		s_mx = 0;
+	}
 	const uint64_t s0 = (pa.start + B - 1) / B, s1 = (pa.start + pa.count) / B; // aligned slots of the parent
 	uint64_t total;
 	const uint64_t c = plan->est_cnt[d];
@@ -526,6 +585,12 @@ __global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restri
 	const uint64_t ns = s1 > s0 ? s1 - s0 : 0;
 	plan->bound[d] = (uint32_t)(s0 + (total ? ex * ns / total : (uint64_t)d * ns / kP));
 	if (d == 0) plan->bound[kP] = (uint32_t)s1;
+	if (d < (1u << pa.width)) {
+		atomicMin(&s_mn, (uint32_t)c);
+		atomicMax(&s_mx, (uint32_t)c);
+	}
+	__syncthreads();
+	if (d == 0 && !(s_mn > 0 && (double)s_mx <= 1.25 * (double)s_mn)) atomicAdd(&ctr->direct_uneven, 1u);
 }
 
 template <typename K, typename V> struct DirectLds {
@@ -572,7 +637,7 @@ __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int 
 template <typename K, typename V>
 __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) void classify_direct_kernel(
 	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
-	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plan, uint8_t *__restrict__ block_map,
+	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plans, uint8_t *__restrict__ block_map,
 	uint8_t *__restrict__ slot_full, uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt,
 	uint32_t *__restrict__ lo_off, K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals,
 	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr)
@@ -617,6 +682,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 	const Parent pa = parents[st.parent];
 	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u;
 	const uint32_t W = pa.stripe_hi - pa.stripe_lo, me = blockIdx.x - pa.stripe_lo;
+	const DirectPlan *plan = plans + st.parent;
 	const uint32_t slot0 = plan->bound[0], slotN = plan->bound[kP];
 
 	// per-bucket state lives in LDS (thread d < kP is the only one to touch bst/fbc of bucket d)

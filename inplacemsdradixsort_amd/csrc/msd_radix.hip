@@ -45,7 +45,8 @@ struct msd_ctx {
 	// direct block placement in the first round: 0 off, 1 when the sampled
 	// children are about equally big, 2 whenever the geometry allows (tests)
 	int direct_mode = 1;
-	uint64_t direct_min = 1ull << 26; // smallest parent it is tried on
+	uint64_t direct_min = 1ull << 26; // smallest round (elements) it is tried on
+	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 };
 
 static int fail(msd_ctx *c, int code, const char *fmt, ...)
@@ -297,7 +298,11 @@ struct RoundBufs {
 	unsigned long long *scan_state;
 	uint32_t *scan_ctr;
 	Segment *next_parents;
+	DirectPlan *plans; // per parent (direct placement)
 };
+
+// direct placement is tried on rounds of at most this many parents
+constexpr size_t kDirectMaxParents = 4096;
 
 template <typename K, typename V>
 static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundBufs &rb)
@@ -340,6 +345,7 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 	rb.scan_ctr = b.take<uint32_t>(4);
 	// children that stay big: each has > small_max elements
 	rb.next_parents = b.take<Segment>(rp.round_keys / (small_max + 1) + 2);
+	rb.plans = b.take<DirectPlan>(np <= kDirectMaxParents ? np : 1);
 }
 
 // scan helper on the context stream
@@ -369,7 +375,6 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 	Bump b(nullptr);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2);
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2); // slot_full (direct placement)
-	b.take<DirectPlan>(1);
 	b.take<Counters>(2); // counters + scratch for the varying-bit reduction
 	b.take<Segment>(n / ((uint64_t)Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT) + 16); // big counting-sort segments
 	return b.off + 4096;
@@ -438,7 +443,6 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	Bump kb(c->keep);
 	uint8_t *block_map = kb.take<uint8_t>(n / B + 2);
 	uint8_t *slot_full = kb.take<uint8_t>(n / B + 2);
-	DirectPlan *dplan = kb.take<DirectPlan>(1);
 	Counters *ctr = kb.take<Counters>(2);
 	const uint32_t big_cap = (uint32_t)std::min<uint64_t>(n / small_max + 16, 0x7FFFFFFFu);
 	Segment *big = kb.take<Segment>(big_cap);
@@ -506,6 +510,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 
 	int round = 0;
+	bool prev_direct = false; // the previous round placed its blocks directly (its digit was evenly spread)
 	while (!cur.empty()) {
 		RoundPlan rp;
 		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits, single_pass ? sp_width : 0u);
@@ -544,39 +549,44 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 		// ---- A: classify (histogram falls out of it)
 		bool direct = false;
-		// (tuples: measured slower than stripe-local classification + full permutation, so only when forced)
-		if ((HV ? c->direct_mode == 2 : c->direct_mode != 0) && !single_pass && np == 1 && rp.parents[0].count >= c->direct_min) {
-			// direct placement: sampled child boundaries; worth it only for about equally big children
-			HIPCHK(c, hipMemsetAsync(dplan, 0, sizeof(DirectPlan), c->stream));
-			// sample about 2^22 keys or more, as runs of 256 spread evenly over the parent
-			const uint64_t nruns = rp.parents[0].count / 256;
-			const uint32_t every = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, nruns / 16384));
-			const uint32_t sgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, nruns / every / 4));
-			hipLaunchKernelGGL((direct_sample_kernel<K>), dim3(sgrid), dim3(256), 0, c->stream, (const K *)keys, rb.parents, dplan, every);
-			HIPCHK(c, hipMemcpyAsync(c->pinned, dplan, sizeof(uint32_t) * kP, hipMemcpyDeviceToHost, c->stream));
+		// Direct placement (DESIGN.md section 2, A'): the first round from a sample, later rounds -- only
+		// after a direct first round -- from exact counts (a read-only pass).  Tuples: measured slower than
+		// stripe-local classification + full permutation, so only when forced.
+		bool try_direct = (HV ? c->direct_mode == 2 : c->direct_mode != 0) && !single_pass && rp.round_keys >= c->direct_min;
+		if (try_direct && np > 1) {
+			try_direct = prev_direct && np <= kDirectMaxParents;
+			for (size_t i = 0; i < np && try_direct; ++i) try_direct = rp.parents[i].count >= c->direct_min_parent;
+		}
+		uint64_t max_piece = 0; // a piece is at most one stripe's share of its parent's slots; the kernel counts it in 16 bits
+		for (size_t i = 0; i < np && try_direct; ++i)
+			max_piece = std::max<uint64_t>(max_piece, rp.parents[i].count / B / (rp.parents[i].stripe_hi - rp.parents[i].stripe_lo) + 2);
+		if (try_direct && max_piece < 65535) {
+			HIPCHK(c, hipMemsetAsync(rb.plans, 0, np * sizeof(DirectPlan), c->stream));
+			HIPCHK(c, hipMemsetAsync(&ctr->direct_uneven, 0, sizeof(uint32_t), c->stream));
+			if (np == 1) {
+				// sample about 2^22 keys or more, as runs of 256 spread evenly over the parent
+				const uint64_t nruns = rp.parents[0].count / 256;
+				const uint32_t every = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, nruns / 16384));
+				const uint32_t sgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, nruns / every / 4));
+				hipLaunchKernelGGL((direct_sample_kernel<K>), dim3(sgrid), dim3(256), 0, c->stream, (const K *)keys, rb.parents, rb.plans, every);
+			} else
+				hipLaunchKernelGGL((direct_hist_kernel<K>), dim3(ns), dim3(1024), 0, c->stream, (const K *)keys, rb.stripes, rb.parents, rb.plans);
+			hipLaunchKernelGGL((direct_plan_kernel<B>), dim3(np), dim3(256), 0, c->stream, rb.parents, rb.plans, ctr);
+			HIPCHK(c, hipMemcpyAsync(c->pinned, &ctr->direct_uneven, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(c, hipStreamSynchronize(c->stream));
-			phase_mark(c, "A sample");
-			const uint32_t *ec = (const uint32_t *)c->pinned;
-			uint32_t mn = ~0u, mx = 0;
-			for (int d = 0; d < (1 << rp.parents[0].width); ++d) {
-				mn = std::min(mn, ec[d]);
-				mx = std::max(mx, ec[d]);
-			}
-			// a piece is at most one stripe's share of the parent's slots; the kernel counts it in 16 bits
-			const uint64_t max_piece = rp.parents[0].count / B / ns + 2;
-			const bool even = mn > 0 && (double)mx <= 1.25 * (double)mn;
-			direct = (even || c->direct_mode == 2) && max_piece < 65535;
+			phase_mark(c, np == 1 ? "A sample" : "A histogram");
+			direct = *(const uint32_t *)c->pinned == 0 || c->direct_mode == 2; // all parents' children about equally big
 			if (direct) {
-				hipLaunchKernelGGL((direct_plan_kernel<B>), dim3(1), dim3(256), 0, c->stream, rb.parents, dplan);
 				constexpr size_t direct_lds = DirectLds<K, V>::bytes;
 				hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
-						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)dplan, block_map, slot_full,
+						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
 						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
 				HIPCHK(c, hipGetLastError());
 				add_stat(c, "direct_rounds", 1);
 				phase_mark(c, "A classify direct");
 			}
 		}
+		prev_direct = direct;
 		if (!direct) {
 			constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
 			hipLaunchKernelGGL((classify_kernel<K, V>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
@@ -1068,6 +1078,9 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "direct_min")) {
 		if (value < 1) return fail(c, MSD_EINVAL, "direct_min must be positive");
 		c->direct_min = (uint64_t)value;
+	} else if (!strcmp(name, "direct_min_parent")) {
+		if (value < 1) return fail(c, MSD_EINVAL, "direct_min_parent must be positive");
+		c->direct_min_parent = (uint64_t)value;
 	} else
 		return fail(c, MSD_EINVAL, "unknown option %s", name);
 	return MSD_OK;
