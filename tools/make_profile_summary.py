@@ -9,7 +9,7 @@ import collections, csv, glob, json, os, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-st = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+st = max(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # newest run
 shutil.copy(st, f"profiles/{rnd}_kernel_stats.csv")
 shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench.json")
 
@@ -23,7 +23,7 @@ def short(name):
 
 acc = {}
 for ctr in ("fetch", "write"):
-    f = glob.glob(os.path.join(src, f"pmc_{ctr}", "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(src, f"pmc_{ctr}", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     per = collections.defaultdict(lambda: [0.0, 0])
     for row in csv.DictReader(open(f)):
         k = short(row["Kernel_Name"])
