@@ -108,13 +108,16 @@ template <typename K> __device__ __forceinline__ uint32_t digit_of(K key, uint32
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 
 // inclusive scan inside a wave
+// (DPP row shifts + row broadcasts: no lane-index registers, unlike a bpermute-based shuffle whose
+// six source-lane addresses the compiler keeps -- and spills -- as loop invariants)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		uint32_t t = __shfl_up(v, o);
-		if ((int)lane_id() >= o) v += t;
-	}
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); // row_shr:1
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); // row_shr:2
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); // row_shr:4
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); // row_shr:8
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1, 3
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2, 3
 	return v;
 }
 __device__ __forceinline__ uint64_t wave_incl_scan64(uint64_t v)
