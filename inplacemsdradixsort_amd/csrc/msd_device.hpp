@@ -1097,6 +1097,14 @@ __device__ __forceinline__ int slot_owner(const uint32_t *is, const uint32_t *ie
 	return -1;
 }
 
+// In a direct-placement round nearly every slot lies in the interior of the bucket its piece belongs
+// to (block_map holds that bucket for every slot of the piece, written or not): try it before searching.
+__device__ __forceinline__ int slot_owner_guess(const uint32_t *is, const uint32_t *ie, uint32_t W, uint32_t i, uint32_t g)
+{
+	if (g < W && is[g] <= i && i < ie[g]) return (int)g;
+	return slot_owner(is, ie, W, i);
+}
+
 // Pass 1 (SCATTER = false): count misplaced blocks per (child, class) and record holes.
 // Pass 2 (SCATTER = true): write the per-child lists, interior-class entries first.
 // Global atomics are issued once per (workgroup, child, class) / once per wave (holes);
@@ -1122,17 +1130,36 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	__syncthreads();
 	const uint32_t nf = nfull[blockIdx.x];
 	const uint32_t nsl = st.slot_hi - st.slot_lo;
+	// Every sweep over the stripe's slots takes 8 consecutive slots per thread with all 16 byte loads
+	// issued before the first is used (one load per iteration made the kernel pure load latency).
+	auto sweep = [&](auto body) {
+		constexpr int U = 8;
+		for (uint32_t o0 = tid * U; o0 < nsl; o0 += 256 * U) {
+			uint32_t bm[U];
+			bool fu[U];
+#pragma unroll
+			for (int u = 0; u < U; ++u) { // branch-free: past-the-end lanes re-read the last slot
+				const uint32_t o = min(o0 + u, nsl - 1u);
+				bm[u] = block_map[st.slot_lo + o];
+				fu[u] = slot_full ? slot_full[st.slot_lo + o] != 0 : o < nf;
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+				if (o0 + u < nsl) body(st.slot_lo + o0 + u, bm[u], fu[u]);
+		}
+	};
+	auto owner_of = [&](uint32_t i, uint32_t d) -> int {
+		return slot_full ? slot_owner_guess(s_is, s_ie, W, i, d) : slot_owner(s_is, s_ie, W, i);
+	};
 	// ---- count (both passes need the per-workgroup counts)
 	uint32_t my_holes = 0;
-	for (uint32_t o = tid; o < nsl; o += 256) {
-		const uint32_t i = st.slot_lo + o;
-		const int own = slot_owner(s_is, s_ie, W, i);
-		if (slot_full ? slot_full[i] != 0 : o < nf) {
-			const uint32_t d = block_map[i];
+	sweep([&](uint32_t i, uint32_t d, bool full) {
+		const int own = owner_of(i, d);
+		if (full) {
 			if ((int)d != own) atomicAdd(&s_cls[own >= 0 ? 0 : 1][d], 1u);
 		} else if (own >= 0)
 			++my_holes;
-	}
+	});
 	if (!SCATTER) { // holes: one global fetch-add per workgroup, positions from an LDS cursor
 		__shared__ uint32_t s_hcount, s_hbase;
 		if (tid == 0) s_hcount = 0;
@@ -1146,16 +1173,15 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 				s_hcount = 0;
 			}
 			__syncthreads();
-			for (uint32_t o = tid; o < nsl; o += 256) {
-				const uint32_t i = st.slot_lo + o;
-				if (slot_full ? slot_full[i] != 0 : o < nf) continue;
-				const int own = slot_owner(s_is, s_ie, W, i);
-				if (own < 0) continue;
+			sweep([&](uint32_t i, uint32_t d, bool full) {
+				if (full) return;
+				const int own = owner_of(i, d);
+				if (own < 0) return;
 				ListEntry e;
 				e.slot = i;
 				e.owner = pa.child_base + (uint32_t)own;
 				holes[s_hbase + atomicAdd(&s_hcount, 1u)] = e;
-			}
+			});
 		}
 	}
 	__syncthreads();
@@ -1176,11 +1202,9 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 		s_cls[1][tid] = 0;
 	}
 	__syncthreads();
-	for (uint32_t o = tid; o < (slot_full ? nsl : (nf < nsl ? nf : nsl)); o += 256) {
-		const uint32_t i = st.slot_lo + o;
-		if (slot_full && !slot_full[i]) continue;
-		const int own = slot_owner(s_is, s_ie, W, i);
-		const uint32_t d = block_map[i];
+	sweep([&](uint32_t i, uint32_t d, bool full) {
+		if (!full) return;
+		const int own = owner_of(i, d);
 		if ((int)d != own) {
 			const uint32_t cls = own >= 0 ? 0 : 1;
 			const uint32_t p = s_base[cls][d] + atomicAdd(&s_cls[cls][d], 1u);
@@ -1189,7 +1213,7 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 			e.owner = own >= 0 ? pa.child_base + (uint32_t)own : kNoOwner;
 			list[p] = e;
 		}
-	}
+	});
 }
 
 // Per child: list length, eviction / excess decisions.
