@@ -552,7 +552,10 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		// Direct placement (DESIGN.md section 2, A'): the first round from a sample, later rounds -- only
 		// after a direct first round -- from exact counts (a read-only pass).  Tuples: measured slower than
 		// stripe-local classification + full permutation, so only when forced.
-		bool try_direct = (HV ? c->direct_mode == 2 : c->direct_mode != 0) && !single_pass && rp.round_keys >= c->direct_min;
+		// (the read schedule hands a bucket one slot per tile: with fewer than 256 buckets the tiles
+		// are not filled, so narrower digits keep the streaming kernel unless forced)
+		bool try_direct = (HV ? c->direct_mode == 2 : c->direct_mode != 0) && rp.round_keys >= c->direct_min;
+		for (size_t i = 0; i < np && try_direct; ++i) try_direct = rp.parents[i].width == 8 || c->direct_mode == 2;
 		if (try_direct && np > 1) {
 			try_direct = prev_direct && np <= kDirectMaxParents;
 			for (size_t i = 0; i < np && try_direct; ++i) try_direct = rp.parents[i].count >= c->direct_min_parent;

@@ -68,7 +68,7 @@ KINDS_EVEN = ["uniform", "sorted", "reversed", "stride", "runs", "lowbits"]
 
 
 @pytest.mark.parametrize("kind", KINDS_EVEN)
-@pytest.mark.parametrize("logn", [20, 22, 23])
+@pytest.mark.parametrize("logn", [22, 23, 24])
 def test_direct_u32_even_buckets(dctx, kind, logn):
     rng = np.random.default_rng(logn * 100 + len(kind))
     n = (1 << logn) + int(rng.integers(0, 200))
@@ -104,7 +104,9 @@ def test_direct_forced_any_distribution(dctx, kind, typ):
 
 
 def test_direct_second_round_u32(dctx):
-    """2^26 keys: the 256 children of the first round (2^18 keys each) are partitioned again, from exact counts."""
+    """2^26 keys: the 256 children of the first round (2^18 keys each) are partitioned again, from exact counts
+    (their digit is 5 bits wide at this size, which only the forced mode places directly)."""
+    dctx.set_option("direct_mode", 2)
     rng = np.random.default_rng(31)
     n = (1 << 26) + 12345
     k = shapes(rng, n, "uniform", 32)
@@ -119,8 +121,7 @@ def test_direct_second_round_u32(dctx):
 @pytest.mark.parametrize("kind", ["uniform", "stride", "runs", "heavy"])
 def test_direct_second_round_u64(dctx, kind):
     """u64 keys need more rounds: at 2^24 the second round has 256 parents of 2^16 keys."""
-    if kind in ("runs", "heavy"):
-        dctx.set_option("direct_mode", 2)
+    dctx.set_option("direct_mode", 2)  # the later rounds' digits are narrower than 8 bits at this size
     rng = np.random.default_rng(41 + len(kind))
     n = (1 << 24) + 777
     k = shapes(rng, n, kind, 64)
@@ -148,9 +149,23 @@ def test_direct_second_round_uneven_children_fall_back(dctx):
     assert (out == k).all()
 
 
+def test_direct_one_digit_partition(dctx):
+    """msd_partition_u32 with an 8-bit digit (the pass before the multi-GPU exchange) places directly too."""
+    rng = np.random.default_rng(61)
+    n = (1 << 22) + 99
+    k = shapes(rng, n, "uniform", 32)
+    t = dev(k)
+    counts = dctx.partition(t, 24, 8).cpu().numpy()
+    assert dctx.stats().get("direct_rounds", 0) == 1, dctx.stats()
+    out = host(t)
+    assert (np.bincount(k >> 24, minlength=256) == counts).all()
+    assert ((out >> 24)[1:] >= (out >> 24)[:-1]).all()
+    assert (np.sort(out) == np.sort(k)).all()
+
+
 def test_direct_unaligned_start_and_odd_length(dctx):
     rng = np.random.default_rng(99)
-    for off, n in [(4, (1 << 20) + 1), (8, (1 << 20) - 63), (12, (1 << 18) + 64)]:
+    for off, n in [(4, (1 << 22) + 1), (8, (1 << 22) - 63), (12, (1 << 20) + 64)]:
         k = shapes(rng, n + off, "uniform", 32)
         t = dev(k)
         dctx.sort_u32(t[off:])
