@@ -50,6 +50,68 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None):
     return out
 
 
+class ShardedSorter:
+    """Pipelined form of :func:`sort_sharded_u32` for a stream of shards (``bench.py --gpus N``).
+
+    ``submit(keys)`` runs the top-digit pass on a shard, exchanges the counts and STARTS the
+    all-to-all into the next receive buffer; ``collect()`` waits for the oldest exchange and sorts
+    what arrived.  Calling ``submit(s)`` before ``collect(s-1)`` lets the exchange of shard s run on
+    RCCL's stream (xGMI) while the compute stream sorts shard s-1 -- the exchange is as long as a
+    local sort, so hiding it is what weak scaling needs.  ``recv_bufs``: at least two buffers (one
+    per exchange in flight plus the one being sorted); the tensor returned by ``collect`` is a view
+    of one of them and is overwritten two submissions later.  ``keys`` must stay untouched until the
+    matching ``collect`` returns.
+    """
+
+    def __init__(self, engine, dist, world: int, recv_bufs, group=None):
+        self.engine, self.dist, self.world, self.group = engine, dist, world, group
+        self.lg = _log2(world)
+        self.recv = list(recv_bufs)
+        if world > 1 and len(self.recv) < 2:
+            raise ValueError("ShardedSorter needs two receive buffers")
+        self._slot = 0
+        self._pending = []
+
+    def _all_to_all(self, out, keys, got_l, send_l):
+        try:      # torch.distributed: returns a Work whose wait() orders the current stream after it
+            return self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l,
+                                               group=self.group, async_op=True)
+        except TypeError:  # stand-ins without async_op (tests)
+            self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=self.group)
+            return None
+
+    def submit(self, keys) -> None:
+        import torch
+        if self.world == 1:
+            self._pending.append((keys, None, keys))
+            return
+        if len(self._pending) >= len(self.recv):
+            raise RuntimeError("collect() before submitting more shards than there are receive buffers")
+        counts = self.engine.partition(keys, 24, 8)
+        send = counts.view(self.world, 256 // self.world).sum(dim=1)
+        got = torch.empty_like(send)
+        self.dist.all_to_all_single(got, send, group=self.group)
+        send_l, got_l = send.tolist(), got.tolist()
+        total = int(sum(got_l))
+        recv = self.recv[self._slot]
+        self._slot = (self._slot + 1) % len(self.recv)
+        if total > recv.numel():
+            raise RuntimeError(f"receive buffer too small: {total} keys for capacity {recv.numel()} "
+                               "(raise the slack, the reference's fudge)")
+        out = recv[:total]
+        self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), keys))
+
+    def collect(self):
+        out, work, _keys = self._pending.pop(0)
+        if work is not None:
+            work.wait()
+        self.engine.sort_u32(out, end_bit=32 - self.lg)
+        return out
+
+    def pending(self) -> int:
+        return len(self._pending)
+
+
 def sort_sharded_u32_sampled(engine, keys, recv, dist, world: int, group=None, sample_per_rank: int = 65536):
     """Skew-robust variant (the reference's own scheme, src/msb_64.c:1511-1564): every rank sorts
     its shard, contributes an equidistant sample of it, all ranks derive the same world-1 equi-depth

@@ -83,6 +83,48 @@ def test_sharded_sort_over_gloo(world, kind):
             assert ((res[r] >> np.uint32(32 - lg)) == r).all()
 
 
+def _pipeline_worker(rank, world, port, n, shards, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inplacemsdradixsort_amd.dist import ShardedSorter
+    from oracle import oracle as O
+    bufs = [torch.from_numpy(O.gen_uniform_u32(n, seed=100 + s, first=rank * n).view(np.int32).copy()) for s in range(shards)]
+    recv = [torch.empty(n * world, dtype=torch.int32) for _ in range(2)]
+    sorter = ShardedSorter(NumpyEngine(), dist, world, recv)
+    outs = []
+    for s in range(shards):        # the order bench.py uses: submit shard s, then finish shard s-1
+        sorter.submit(bufs[s])
+        if s:
+            outs.append(sorter.collect().numpy().view(np.uint32).copy())
+    outs.append(sorter.collect().numpy().view(np.uint32).copy())
+    assert sorter.pending() == 0
+    q.put((rank, outs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_pipelined_sharded_sorter_over_gloo(world):
+    """ShardedSorter (exchange of shard s in flight while shard s-1 is sorted) gives every shard's sorted ranges."""
+    n, shards = 12000, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, n, shards, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    for s in range(shards):
+        allk = np.concatenate([O.gen_uniform_u32(n, seed=100 + s, first=r * n) for r in range(world)])
+        got = np.concatenate([res[r][s] for r in range(world)])
+        assert (got == O.sort_u32(allk)).all(), s
+
+
 @pytest.mark.parametrize("world,kind", [(2, "zipf"), (4, "zipf"), (4, "uniform")])
 def test_sampled_splitter_sort_over_gloo(world, kind):
     """Skew path: equi-depth splitters with the reference's duplicate rule; ranks stay balanced on Zipf keys."""

@@ -64,6 +64,69 @@ def _worker(rank, world, port, n, kind, q, sampled=False):
     ctx.close()
 
 
+def _pipeline_worker(rank, world, port, n, shards, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inplacemsdradixsort_amd import MsdContext
+    from inplacemsdradixsort_amd.dist import ShardedSorter
+    ctx = MsdContext(0)
+    ctx.set_option("direct_min", 1 << 16)   # the pre-exchange pass and the local sorts place directly at this size
+    bufs, sums = [], []
+    for s in range(shards):
+        t = torch.empty(n, dtype=torch.int32, device="cuda:0")
+        ctx.gen_uniform_u32(t, seed=500 + s, first=rank * n)
+        bufs.append(t)
+        sums.append(ctx.check(t)[1:])
+    recv = [torch.empty(n * world, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    sorter = ShardedSorter(ctx, GlooViaCpu, world, recv)
+    res = []
+
+    def take(out):
+        v, s_, x_ = ctx.check(out)
+        lo = int(out[0].item()) & 0xFFFFFFFF if out.numel() else -1
+        hi = int(out[-1].item()) & 0xFFFFFFFF if out.numel() else -1
+        res.append((out.numel(), v, s_, x_, lo, hi))
+
+    for s in range(shards):
+        sorter.submit(bufs[s])
+        if s:
+            take(sorter.collect())
+    take(sorter.collect())
+    q.put((rank, res, sums))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_pipelined_sharded_sorter_real_engine():
+    """bench.py's N > 1 loop (ShardedSorter) with the HIP engine: 2 ranks on one device, 3 shards in a row."""
+    world, n, shards = 2, 1 << 22, 3
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_pipeline_worker, args=(r, world, port, n, shards, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for s in range(shards):
+        per_rank = [got[r][1][s] for r in range(world)]
+        assert sum(x[0] for x in per_rank) == n * world
+        assert all(x[1] == 0 for x in per_rank)                       # every rank's range is sorted
+        in_sum = sum(got[r][2][s][0] for r in range(world)) & (2 ** 64 - 1)
+        in_xor = 0
+        for r in range(world):
+            in_xor ^= got[r][2][s][1]
+        out_xor = 0
+        for x in per_rank:
+            out_xor ^= x[3]
+        assert sum(x[2] for x in per_rank) & (2 ** 64 - 1) == in_sum and out_xor == in_xor
+        assert per_rank[0][5] < per_rank[1][4]                        # rank 0's range precedes rank 1's
+
+
 @pytest.mark.parametrize("world,kind,n", [(2, "uniform", 1 << 22), (4, "uniform", 1 << 20), (2, "zipf", 1 << 21)])
 def test_sharded_sort_real_engine(world, kind, n):
     mpc = mp.get_context("spawn")
