@@ -1553,10 +1553,14 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 	uint32_t *nexti = wtot + 17;
 	K *hi_l = reinterpret_cast<K *>(wtot + 18); // 8 bytes
 	uint32_t *tfree = wtot + 20;
+	uint32_t *crowded = wtot + 21;                          // some thread owns more than 255 keys
+	uint32_t *tbase = reinterpret_cast<uint32_t *>(stage);  // per-thread output base (fast path, before the stage is used)
+	K *out = reinterpret_cast<K *>(smem);                   // fast path: counters + stage as one output buffer
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	if (blockIdx.x >= nsegs) return;
 	Segment sg = segs[blockIdx.x];
 	K pk[kCountPf];
+	uint32_t rk[kCountPf]; // fast path: counted value (low 16 bits) | rank among equal keys, then output position (high 16)
 	auto prefetch = [&](const Segment &g) {
 		const K *src = keys + g.start;
 		const uint32_t cnt = (uint32_t)g.count;
@@ -1574,16 +1578,34 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 		K *seg = keys + sg.start;
 
 		for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
-		if (tid == 0) *nexti = atomicAdd(&ctr->count_ticket, 1u) + gridDim.x;
+		if (tid == 0) {
+			*nexti = atomicAdd(&ctr->count_ticket, 1u) + gridDim.x;
+			*crowded = 0;
+		}
 		__syncthreads();
 		// A byte that overflows carries into its neighbour: the sum of all bytes then falls short of
 		// n (every carry loses 255 or 256), which the prefix sums below notice -- no per-key check.
+		// A segment whose keys are all in registers keeps each fetch-add's return value: the key's rank
+		// among equal keys, which with the counters' prefix sums is its output position (fast path).
+		const bool in_regs = n <= (uint32_t)(kCountPf * kCountTh);
+		if (in_regs) {
 #pragma unroll
-		for (int u = 0; u < kCountPf; ++u) {
-			const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
-			if (tid < left) {
-				const uint32_t v = (uint32_t)pk[u] & mask;
-				atomicAdd(&cw[cw_at(v >> 2)], 1u << ((v & 3u) * 8u));
+			for (int u = 0; u < kCountPf; ++u) {
+				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+				rk[u] = 0;
+				if (tid < left) {
+					const uint32_t v = (uint32_t)pk[u] & mask, sh = (v & 3u) * 8u;
+					rk[u] = v | (((atomicAdd(&cw[cw_at(v >> 2)], 1u << sh) >> sh) & 0xFFu) << 16);
+				}
+			}
+		} else {
+#pragma unroll
+			for (int u = 0; u < kCountPf; ++u) {
+				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+				if (tid < left) {
+					const uint32_t v = (uint32_t)pk[u] & mask;
+					atomicAdd(&cw[cw_at(v >> 2)], 1u << ((v & 3u) * 8u));
+				}
 			}
 		}
 		if (tid == 0) *hi_l = pk[0] & ~(K)mask; // common prefix of the whole segment
@@ -1614,16 +1636,11 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 		const uint32_t w0 = tid * wpt;
 		const uint32_t *cwp = cw + cw_at(w0);
 		uint32_t tot = 0;
-		uint64_t nz = 0; // one bit per non-empty byte counter of this thread
 		if (w0 < nwords) {
 #pragma unroll 4
-			for (uint32_t j = 0; j < wpt; ++j) {
-				const uint32_t x = cwp[j];
-				tot = __builtin_amdgcn_sad_u8(x, 0u, tot); // byte sum
-				const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
-				nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
-			}
+			for (uint32_t j = 0; j < wpt; ++j) tot = __builtin_amdgcn_sad_u8(cwp[j], 0u, tot); // byte sum
 		}
+		if (tot > 255u) *crowded = 1;
 		const uint32_t inc = wave_incl_scan(tot);
 		if (lane == 63) wtot[w] = inc;
 		__syncthreads();
@@ -1644,7 +1661,56 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 					if (at < big_cap) big[at] = sg; else atomicAdd(&ctr->errors, 1u);
 				}
 			}
+		} else if (in_regs && *crowded == 0) {
+			// ---- fast path: every key goes straight to its place.  Each thread turns its counters into
+			// exclusive prefix sums relative to its own first output position (they fit a byte: the thread
+			// owns at most 255 keys), publishes that position, and a key's place is
+			// base[owner of its value] + prefix[value] + its rank among equal keys.
+			uint32_t *cww = cw + cw_at(w0);
+			uint32_t run = 0;
+			if (w0 < nwords) {
+#pragma unroll 4
+				for (uint32_t j = 0; j < wpt; ++j) {
+					const uint32_t x = cww[j], y = x * 0x01010101u; // bytes of y: inclusive sums inside the word
+					cww[j] = (y - x) + run * 0x01010101u;
+					run += y >> 24;
+				}
+			}
+			tbase[tid] = pos;
+			__syncthreads();
+			const uint32_t lgw = (uint32_t)__builtin_ctz(wpt);
+#pragma unroll
+			for (int u = 0; u < kCountPf; ++u) {
+				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+				if (tid < left) { // (positions are below 2^15: the segment has at most 17 Ki keys)
+					const uint32_t v = rk[u] & 0xFFFFu, wi = v >> 2;
+					rk[u] += (tbase[wi >> lgw] + ((cw[cw_at(wi)] >> ((v & 3u) * 8u)) & 0xFFu)) << 16;
+				}
+			}
+			__syncthreads(); // counters and bases are dead: everything up to the stage's end is the output buffer
+#pragma unroll
+			for (int u = 0; u < kCountPf; ++u) {
+				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+				if (tid < left) out[rk[u] >> 16] = hi | (K)(rk[u] & 0xFFFFu);
+			}
+			__syncthreads();
+			if (nxt < nsegs) { // the next segment's keys travel while this one is stored
+				nsg = segs[nxt];
+				prefetch(nsg);
+				fetched = true;
+			}
+			for (uint32_t i = tid; i < n; i += kCountTh) seg[i] = out[i];
+			__syncthreads();
 		} else {
+			uint64_t nz = 0; // one bit per non-empty byte counter of this thread
+			if (w0 < nwords) {
+#pragma unroll 4
+				for (uint32_t j = 0; j < wpt; ++j) {
+					const uint32_t x = cwp[j];
+					const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
+					nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
+				}
+			}
 			const uint32_t end = pos + tot;
 			const K hi4 = hi | (K)(w0 * 4u);
 			// ---- re-generate the sorted keys window by window through LDS (coalesced stores).
