@@ -39,7 +39,7 @@ KERNEL_ALGO = {
     "A histogram": ("direct_hist_kernel<u32>", 4.0),
     "B block permute": ("chains_kernel<u32>", 6.0),    # per key per round
     "LDS sort": ("lds_sort_kernel<u32>", None),        # remaining passes x 12 B per key
-    "count sort": ("count_sort_kernel<u32>", None),    # remaining passes x 12 B per key
+    "count sort": ("count_place_kernel<u32>", None),   # remaining passes x 12 B per key
 }
 
 

@@ -95,7 +95,9 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t nbig;         // cumulative: segments of any size with <= 16 bits left (multi-workgroup counting sort)
 	uint32_t count_ticket; // work ticket of the persistent counting-sort workgroups
 	uint32_t direct_uneven; // per round: parents whose children are too unequal for direct placement
-	uint32_t pad[1];
+	uint32_t nslow;         // counting-sort segments the fast kernel left to count_walk_kernel
+	uint32_t count_ticket2; // work ticket of count_walk_kernel
+	uint32_t pad[3];
 };
 
 // ---------------------------------------------------------------- utilities
@@ -1535,37 +1537,51 @@ constexpr int kCountStageBytes = 14080; // output window; with the counters: two
 constexpr size_t kCountLds = kCountCwBytes + kCountStageBytes + 128; // 128: wave totals, flag, ticket, prefix
 __device__ __forceinline__ uint32_t cw_at(uint32_t i) { return i + (i >> 5); }
 
-// Persistent workgroups: each takes segments by ticket and loads the first 16 keys per thread of
-// its NEXT segment before it re-generates the current one, so the load latency of a segment
-// (the largest part of a 16 Ki-key segment's life) is hidden behind the previous one's work.
+// Persistent workgroups: each takes segments by ticket and loads the first keys of its NEXT segment
+// while it stores the current one.  Two kernels share the counting phase:
+//  * count_place_kernel (the fast path): a segment whose keys all sit in registers (<= 17 Ki u32) keeps
+//    each fetch-add's return value, the key's rank among equal keys.  Every thread then turns its counter
+//    bytes into exclusive prefix sums relative to its own first output position (they fit a byte as long
+//    as a thread owns <= 255 keys) and publishes that position; a key's place is
+//    base[owner of its value] + prefix[value] + rank, and all keys are written at once into an output
+//    buffer that takes over the counters' LDS.  Segments it cannot take (too long, a thread with > 255
+//    keys, a byte overflow) are queued untouched for
+//  * count_walk_kernel: no ranks; every thread walks its own counters and re-generates its run of the
+//    output window by window (the windows grow into the counter words already consumed).
+struct CountLds {
+	uint32_t *cw;     // packed byte counters (padded layout)
+	uint32_t *wtot;   // 16 wave totals
+	uint32_t *nexti;  // next ticket
+	uint32_t *tfree;  // walk: the thread cut by the window's end
+	uint32_t *crowded; // place: some thread owns more than 255 keys
+};
+
 template <typename K>
-__global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__ keys,
-	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ fallback, uint32_t fallback_base,
-	uint32_t lds_cap, Segment *__restrict__ big, uint32_t big_cap, Counters *__restrict__ ctr)
+__global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict__ keys,
+	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ slow, Counters *__restrict__ ctr)
 {
-	constexpr uint32_t WS = kCountStageBytes / sizeof(K); // keys per output window
 	// keys per thread held in registers: a little more than 2^14 / 1024, the typical segment
-	constexpr int kCountPf = sizeof(K) == 4 ? 17 : 9;
+	constexpr int PF = sizeof(K) == 4 ? 17 : 9;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);    // packed byte counters (padded layout)
-	K *stage = reinterpret_cast<K *>(smem + kCountCwBytes);
-	uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + kCountCwBytes + kCountStageBytes); // 16 wave totals
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);
+	uint32_t *tbase = reinterpret_cast<uint32_t *>(smem + kCountCwBytes); // per-thread output base (before the buffer is used)
+	K *out = reinterpret_cast<K *>(smem);                                  // counters + stage as one output buffer
+	uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + kCountCwBytes + kCountStageBytes);
 	uint32_t *nexti = wtot + 17;
 	K *hi_l = reinterpret_cast<K *>(wtot + 18); // 8 bytes
-	uint32_t *tfree = wtot + 20;
-	uint32_t *crowded = wtot + 21;                          // some thread owns more than 255 keys
-	uint32_t *tbase = reinterpret_cast<uint32_t *>(stage);  // per-thread output base (fast path, before the stage is used)
-	K *out = reinterpret_cast<K *>(smem);                   // fast path: counters + stage as one output buffer
+	uint32_t *crowded = wtot + 21;
+	static_assert((size_t)PF * kCountTh * sizeof(K) <= kCountCwBytes + kCountStageBytes, "output buffer");
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	if (blockIdx.x >= nsegs) return;
 	Segment sg = segs[blockIdx.x];
-	K pk[kCountPf];
-	uint32_t rk[kCountPf]; // fast path: counted value (low 16 bits) | rank among equal keys, then output position (high 16)
+	K pk[PF];
 	auto prefetch = [&](const Segment &g) {
 		const K *src = keys + g.start;
-		const uint32_t cnt = (uint32_t)g.count;
+		// branch-free (a conditional prefetch makes the compiler wait for the loads where they are issued):
+		// out-of-range lanes re-read the last key, a segment too long for the fast path only its first key
+		const uint32_t cnt = g.count <= (uint64_t)(PF * kCountTh) ? (uint32_t)g.count : 1u;
 #pragma unroll
-		for (int u = 0; u < kCountPf; ++u) { // branch-free: out-of-range lanes re-read the last key (ignored when counting)
+		for (int u = 0; u < PF; ++u) {
 			const uint32_t idx = min((uint32_t)(u * kCountTh) + tid, cnt - 1u);
 			pk[u] = src[idx];
 		}
@@ -1576,21 +1592,21 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 		const uint32_t nv = 1u << sg.bits, mask = nv - 1u;
 		const uint32_t nwords = nv >= 4 ? nv / 4 : 1;
 		K *seg = keys + sg.start;
+		const bool in_regs = n <= (uint32_t)(PF * kCountTh);
 
-		for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
+		if (in_regs)
+			for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
 		if (tid == 0) {
 			*nexti = atomicAdd(&ctr->count_ticket, 1u) + gridDim.x;
 			*crowded = 0;
+			*hi_l = pk[0] & ~(K)mask; // common prefix of the whole segment
 		}
 		__syncthreads();
-		// A byte that overflows carries into its neighbour: the sum of all bytes then falls short of
-		// n (every carry loses 255 or 256), which the prefix sums below notice -- no per-key check.
-		// A segment whose keys are all in registers keeps each fetch-add's return value: the key's rank
-		// among equal keys, which with the counters' prefix sums is its output position (fast path).
-		const bool in_regs = n <= (uint32_t)(kCountPf * kCountTh);
+		// value (low 16 bits) | rank among equal keys, later | output position (high 16 bits)
+		uint32_t rk[PF];
 		if (in_regs) {
 #pragma unroll
-			for (int u = 0; u < kCountPf; ++u) {
+			for (int u = 0; u < PF; ++u) {
 				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
 				rk[u] = 0;
 				if (tid < left) {
@@ -1598,29 +1614,117 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 					rk[u] = v | (((atomicAdd(&cw[cw_at(v >> 2)], 1u << sh) >> sh) & 0xFFu) << 16);
 				}
 			}
-		} else {
-#pragma unroll
-			for (int u = 0; u < kCountPf; ++u) {
-				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
-				if (tid < left) {
-					const uint32_t v = (uint32_t)pk[u] & mask;
-					atomicAdd(&cw[cw_at(v >> 2)], 1u << ((v & 3u) * 8u));
+		}
+		__syncthreads();
+		const uint32_t nxt = *nexti;
+		const K hi = *hi_l;
+		// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
+		// (wpt divides 32, so the owned words are consecutive in the padded layout too)
+		const uint32_t wpt = nwords >= kCountTh ? nwords / kCountTh : 1;
+		const uint32_t w0 = tid * wpt;
+		uint32_t *cww = cw + cw_at(w0);
+		uint32_t tot = 0;
+		if (in_regs && w0 < nwords) {
+#pragma unroll 4
+			for (uint32_t j = 0; j < wpt; ++j) tot = __builtin_amdgcn_sad_u8(cww[j], 0u, tot); // byte sum
+		}
+		if (tot > 255u) *crowded = 1;
+		const uint32_t inc = wave_incl_scan(tot);
+		if (lane == 63) wtot[w] = inc;
+		__syncthreads();
+		uint32_t pos = inc - tot, all = 0;
+#pragma unroll 2
+		for (uint32_t ww = 0; ww < kCountTh / 64; ++ww) {
+			const uint32_t t = wtot[ww];
+			if (ww < w) pos += t;
+			all += t;
+		}
+		// a byte that overflowed carried into its neighbour: the sum of all bytes then falls short of n
+		const bool ok = in_regs && all == n && *crowded == 0;
+		if (ok) {
+			uint32_t run = 0;
+			if (w0 < nwords) {
+#pragma unroll 4
+				for (uint32_t j = 0; j < wpt; ++j) {
+					const uint32_t x = cww[j], y = x * 0x01010101u; // bytes of y: inclusive sums inside the word
+					cww[j] = (y - x) + run * 0x01010101u;
+					run += y >> 24;
 				}
 			}
-		}
-		if (tid == 0) *hi_l = pk[0] & ~(K)mask; // common prefix of the whole segment
-		for (uint32_t i0 = kCountPf * kCountTh; i0 < n; i0 += 4 * kCountTh) { // segments above 16 Ki keys
-			K k4[4];
+			tbase[tid] = pos;
+			__syncthreads();
+			const uint32_t lgw = (uint32_t)__builtin_ctz(wpt);
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint32_t idx = i0 + u * kCountTh + tid;
-				k4[u] = idx < n ? seg[idx] : (K)0;
+			for (int u = 0; u < PF; ++u) {
+				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+				if (tid < left) { // (positions are below 2^15: the segment has at most 17 Ki keys)
+					const uint32_t v = rk[u] & 0xFFFFu, wi = v >> 2;
+					rk[u] += (tbase[wi >> lgw] + ((cw[cw_at(wi)] >> ((v & 3u) * 8u)) & 0xFFu)) << 16;
+				}
 			}
+			__syncthreads(); // counters and bases are dead: everything up to the stage's end is the output buffer
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint32_t idx = i0 + u * kCountTh + tid;
-				if (idx < n) {
-					const uint32_t v = (uint32_t)k4[u] & mask;
+			for (int u = 0; u < PF; ++u) {
+				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
+				if (tid < left) out[rk[u] >> 16] = hi | (K)(rk[u] & 0xFFFFu);
+			}
+			__syncthreads();
+		} else if (tid == 0)
+			slow[atomicAdd(&ctr->nslow, 1u)] = sg; // untouched
+		Segment nsg = sg;
+		if (nxt < nsegs) { // the next segment's keys travel while this one is stored
+			nsg = segs[nxt];
+			prefetch(nsg);
+		}
+		if (ok) {
+			for (uint32_t i = tid; i < n; i += kCountTh) seg[i] = out[i];
+		}
+		if (nxt >= nsegs) break;
+		sg = nsg;
+		__syncthreads(); // the output buffer is cleared next
+	}
+}
+
+template <typename K>
+__global__ __launch_bounds__(kCountTh, 8) void count_walk_kernel(K *__restrict__ keys,
+	const Segment *__restrict__ segs, const uint32_t *__restrict__ nsegs_dev, Segment *__restrict__ fallback,
+	uint32_t fallback_base, uint32_t lds_cap, Segment *__restrict__ big, uint32_t big_cap, Counters *__restrict__ ctr)
+{
+	constexpr uint32_t WS = kCountStageBytes / sizeof(K); // keys per output window
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);    // packed byte counters (padded layout)
+	K *stage = reinterpret_cast<K *>(smem + kCountCwBytes);
+	uint32_t *wtot = reinterpret_cast<uint32_t *>(smem + kCountCwBytes + kCountStageBytes); // 16 wave totals
+	uint32_t *nexti = wtot + 17;
+	K *hi_l = reinterpret_cast<K *>(wtot + 18); // 8 bytes
+	uint32_t *tfree = wtot + 20;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t nsegs = *nsegs_dev;
+	if (blockIdx.x >= nsegs) return;
+	Segment sg = segs[blockIdx.x];
+	for (;;) {
+		const uint32_t n = (uint32_t)sg.count;
+		const uint32_t nv = 1u << sg.bits, mask = nv - 1u;
+		const uint32_t nwords = nv >= 4 ? nv / 4 : 1;
+		K *seg = keys + sg.start;
+
+		for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
+		if (tid == 0) {
+			*nexti = atomicAdd(&ctr->count_ticket2, 1u) + gridDim.x;
+			*hi_l = seg[0] & ~(K)mask; // common prefix of the whole segment
+		}
+		__syncthreads();
+		// A byte that overflows carries into its neighbour: the sum of all bytes then falls short of
+		// n (every carry loses 255 or 256), which the prefix sums below notice -- no per-key check.
+		constexpr int LB = 16 / (int)sizeof(K) * 4; // loads in flight per thread (branch-free, clamped)
+		for (uint32_t i0 = 0; i0 < n; i0 += LB * kCountTh) {
+			K kb[LB];
+#pragma unroll
+			for (int u = 0; u < LB; ++u) kb[u] = seg[min(i0 + u * kCountTh + tid, n - 1u)];
+#pragma unroll
+			for (int u = 0; u < LB; ++u) {
+				if (i0 + u * kCountTh + tid < n) {
+					const uint32_t v = (uint32_t)kb[u] & mask;
 					atomicAdd(&cw[cw_at(v >> 2)], 1u << ((v & 3u) * 8u));
 				}
 			}
@@ -1628,19 +1732,22 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 		__syncthreads();
 		const uint32_t nxt = *nexti;
 		const K hi = *hi_l;
-		Segment nsg = sg;
-		bool fetched = false;
 		// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
 		// (wpt divides 32, so the owned words are consecutive in the padded layout too)
 		const uint32_t wpt = nwords >= kCountTh ? nwords / kCountTh : 1;
 		const uint32_t w0 = tid * wpt;
 		const uint32_t *cwp = cw + cw_at(w0);
 		uint32_t tot = 0;
+		uint64_t nz = 0; // one bit per non-empty byte counter of this thread
 		if (w0 < nwords) {
 #pragma unroll 4
-			for (uint32_t j = 0; j < wpt; ++j) tot = __builtin_amdgcn_sad_u8(cwp[j], 0u, tot); // byte sum
+			for (uint32_t j = 0; j < wpt; ++j) {
+				const uint32_t x = cwp[j];
+				tot = __builtin_amdgcn_sad_u8(x, 0u, tot); // byte sum
+				const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
+				nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
+			}
 		}
-		if (tot > 255u) *crowded = 1;
 		const uint32_t inc = wave_incl_scan(tot);
 		if (lane == 63) wtot[w] = inc;
 		__syncthreads();
@@ -1661,56 +1768,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 					if (at < big_cap) big[at] = sg; else atomicAdd(&ctr->errors, 1u);
 				}
 			}
-		} else if (in_regs && *crowded == 0) {
-			// ---- fast path: every key goes straight to its place.  Each thread turns its counters into
-			// exclusive prefix sums relative to its own first output position (they fit a byte: the thread
-			// owns at most 255 keys), publishes that position, and a key's place is
-			// base[owner of its value] + prefix[value] + its rank among equal keys.
-			uint32_t *cww = cw + cw_at(w0);
-			uint32_t run = 0;
-			if (w0 < nwords) {
-#pragma unroll 4
-				for (uint32_t j = 0; j < wpt; ++j) {
-					const uint32_t x = cww[j], y = x * 0x01010101u; // bytes of y: inclusive sums inside the word
-					cww[j] = (y - x) + run * 0x01010101u;
-					run += y >> 24;
-				}
-			}
-			tbase[tid] = pos;
-			__syncthreads();
-			const uint32_t lgw = (uint32_t)__builtin_ctz(wpt);
-#pragma unroll
-			for (int u = 0; u < kCountPf; ++u) {
-				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
-				if (tid < left) { // (positions are below 2^15: the segment has at most 17 Ki keys)
-					const uint32_t v = rk[u] & 0xFFFFu, wi = v >> 2;
-					rk[u] += (tbase[wi >> lgw] + ((cw[cw_at(wi)] >> ((v & 3u) * 8u)) & 0xFFu)) << 16;
-				}
-			}
-			__syncthreads(); // counters and bases are dead: everything up to the stage's end is the output buffer
-#pragma unroll
-			for (int u = 0; u < kCountPf; ++u) {
-				const uint32_t left = n > (uint32_t)(u * kCountTh) ? n - u * kCountTh : 0u;
-				if (tid < left) out[rk[u] >> 16] = hi | (K)(rk[u] & 0xFFFFu);
-			}
-			__syncthreads();
-			if (nxt < nsegs) { // the next segment's keys travel while this one is stored
-				nsg = segs[nxt];
-				prefetch(nsg);
-				fetched = true;
-			}
-			for (uint32_t i = tid; i < n; i += kCountTh) seg[i] = out[i];
-			__syncthreads();
 		} else {
-			uint64_t nz = 0; // one bit per non-empty byte counter of this thread
-			if (w0 < nwords) {
-#pragma unroll 4
-				for (uint32_t j = 0; j < wpt; ++j) {
-					const uint32_t x = cwp[j];
-					const uint32_t hb = (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u; // bit 7 of each non-zero byte
-					nz |= (uint64_t)((((hb >> 7) * 0x01020408u) >> 24) & 0xFu) << (4u * j);
-				}
-			}
 			const uint32_t end = pos + tot;
 			const K hi4 = hi | (K)(w0 * 4u);
 			// ---- re-generate the sorted keys window by window through LDS (coalesced stores).
@@ -1743,26 +1801,15 @@ __global__ __launch_bounds__(kCountTh, 8) void count_sort_kernel(K *__restrict__
 				return (uint32_t)(cw_at(tf * wpt) * 4u / sizeof(K)); // keys that fit below thread tf's counters
 			};
 			uint32_t wbeg = 0, wend = WS < n ? WS : n;
-			while (wend < n) {
+			for (;;) {
 				const uint32_t room = window(wbeg, wend);
+				if (wend >= n) break;
 				wbeg = wend;
 				wend = wbeg + WS + room < n ? wbeg + WS + room : n;
 			}
-			// the next segment's first keys travel while the last window is written (their registers
-			// are free only now, and are needed again right after the counters are cleared)
-			if (nxt < nsegs) {
-				nsg = segs[nxt];
-				prefetch(nsg);
-				fetched = true;
-			}
-			window(wbeg, wend);
-		}
-		if (!fetched && nxt < nsegs) {
-			nsg = segs[nxt];
-			prefetch(nsg);
 		}
 		if (nxt >= nsegs) break;
-		sg = nsg;
+		sg = segs[nxt];
 		__syncthreads(); // nexti / hi_l / wtot are rewritten next
 	}
 }

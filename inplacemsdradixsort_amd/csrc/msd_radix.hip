@@ -673,10 +673,16 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	constexpr size_t sort_lds = SortLds<K, V>::bytes;
 	if constexpr (!HV) {
 		if (ncount_host && !single_pass) {
-			// persistent workgroups (two per CU fit the LDS), segments handed out by ticket
+			// persistent workgroups (two per CU fit the LDS), segments handed out by ticket; what the fast
+			// kernel cannot place directly is queued (in the round slab, dead by now) for the walking kernel
+			int rcs = slab_reserve(c, (size_t)ncount_host * sizeof(Segment) + 4096);
+			if (rcs) return rcs;
+			Segment *slow = reinterpret_cast<Segment *>(c->slab);
 			const uint32_t count_grid = std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count * 2);
-			hipLaunchKernelGGL((count_sort_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
-					   keys, small_count, ncount_host, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
+			hipLaunchKernelGGL((count_place_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
+					   keys, small_count, ncount_host, slow, ctr);
+			hipLaunchKernelGGL((count_walk_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
+					   keys, slow, &ctr->nslow, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
 			HIPCHK(c, hipGetLastError());
 			phase_mark(c, "count sort");
 			// byte-counter overflows of segments above the LDS-sort capacity joined the big list
@@ -784,7 +790,9 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
-		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_sort_kernel<K>),
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_place_kernel<K>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_walk_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&bigcount_hist_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBigHistLds));
