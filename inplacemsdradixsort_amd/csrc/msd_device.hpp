@@ -939,7 +939,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 			}
 		}
 		__syncthreads(); // B3
+#ifndef MSD_EXP_NOWAIT
 		__builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
 		nc = tmp[12 + par];
 		okc = load_tile(kc, vc);
 		// ---- flush completed buffers to their slots
@@ -1132,22 +1134,41 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	__syncthreads();
 	const uint32_t nf = nfull[blockIdx.x];
 	const uint32_t nsl = st.slot_hi - st.slot_lo;
-	// Every sweep over the stripe's slots takes 8 consecutive slots per thread with all 16 byte loads
-	// issued before the first is used (one load per iteration made the kernel pure load latency).
+	// Every sweep over the stripe's slots takes groups of 8 consecutive slots per thread, read with one
+	// aligned 8-byte load per map (byte loads are processed lane by lane: sixteen of them per 8 slots
+	// made the kernel's time), two groups in flight; the few slots before the first 8-aligned one and
+	// after the last whole group go one per thread.
 	auto sweep = [&](auto body) {
-		constexpr int U = 8;
-		for (uint32_t o0 = tid * U; o0 < nsl; o0 += 256 * U) {
-			uint32_t bm[U];
-			bool fu[U];
+		const uint32_t lead = min(nsl, (8u - (st.slot_lo & 7u)) & 7u);
+		const uint32_t ngr = (nsl - lead) / 8u, rest = lead + 8u * ngr;
+		auto one = [&](uint32_t o) {
+			const uint32_t i = st.slot_lo + o;
+			body(i, (uint32_t)block_map[i], slot_full ? slot_full[i] != 0 : o < nf);
+		};
+		if (tid < lead) one(tid);
+		if (tid < nsl - rest) one(rest + tid);
+		for (uint32_t g0 = tid; g0 < ngr; g0 += 2 * 256) {
+			uint2 bm[2], sf[2];
 #pragma unroll
-			for (int u = 0; u < U; ++u) { // branch-free: past-the-end lanes re-read the last slot
-				const uint32_t o = min(o0 + u, nsl - 1u);
-				bm[u] = block_map[st.slot_lo + o];
-				fu[u] = slot_full ? slot_full[st.slot_lo + o] != 0 : o < nf;
+			for (int k = 0; k < 2; ++k) { // branch-free: a thread without a second group re-reads the last one
+				const uint32_t g = min(g0 + k * 256u, ngr - 1u);
+				const size_t at = (size_t)st.slot_lo + lead + 8u * g;
+				bm[k] = *reinterpret_cast<const uint2 *>(block_map + at);
+				sf[k] = slot_full ? *reinterpret_cast<const uint2 *>(slot_full + at) : make_uint2(0u, 0u);
 			}
 #pragma unroll
-			for (int u = 0; u < U; ++u)
-				if (o0 + u < nsl) body(st.slot_lo + o0 + u, bm[u], fu[u]);
+			for (int k = 0; k < 2; ++k) {
+				const uint32_t g = g0 + k * 256u;
+				if (g < ngr) {
+#pragma unroll
+					for (int u = 0; u < 8; ++u) {
+						const uint32_t o = lead + 8u * g + u;
+						const uint32_t b = ((u < 4 ? bm[k].x : bm[k].y) >> (8 * (u & 3))) & 0xFFu;
+						const uint32_t f = ((u < 4 ? sf[k].x : sf[k].y) >> (8 * (u & 3))) & 0xFFu;
+						body(st.slot_lo + o, b, slot_full ? f != 0 : o < nf);
+					}
+				}
+			}
 		}
 	};
 	auto owner_of = [&](uint32_t i, uint32_t d) -> int {
