@@ -1113,6 +1113,7 @@ __device__ __forceinline__ int slot_owner_guess(const uint32_t *is, const uint32
 // Pass 2 (SCATTER = true): write the per-child lists, interior-class entries first.
 // Global atomics are issued once per (workgroup, child, class) / once per wave (holes);
 // positions inside a reservation come from LDS fetch-adds.
+constexpr uint32_t kSlotParts = 4;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, const uint8_t *__restrict__ block_map,
@@ -1122,7 +1123,10 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	// slot_full == nullptr: a stripe's first nfull slots hold blocks (streaming classify);
 	// otherwise a byte per slot says whether it holds a block (direct placement)
 	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP], s_base[2][kP];
-	const Stripe st = stripes[blockIdx.x];
+	// kSlotParts workgroups share a stripe (each a contiguous part of its slots): the sweeps are short
+	// latency-bound loops, so more, smaller workgroups finish sooner; counts and list ranges are
+	// combined across workgroups by atomics anyway
+	Stripe st = stripes[blockIdx.x / kSlotParts];
 	const Parent pa = parents[st.parent];
 	const uint32_t W = 1u << pa.width, tid = threadIdx.x;
 	if (tid < W) {
@@ -1132,7 +1136,14 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	s_cls[0][tid] = 0;
 	s_cls[1][tid] = 0;
 	__syncthreads();
-	const uint32_t nf = nfull[blockIdx.x];
+	uint32_t nf = nfull[blockIdx.x / kSlotParts]; // streaming classify: the stripe's first nf slots hold blocks
+	{
+		const uint32_t all = st.slot_hi - st.slot_lo, part = blockIdx.x % kSlotParts;
+		const uint32_t a = (uint32_t)((uint64_t)all * part / kSlotParts), b = (uint32_t)((uint64_t)all * (part + 1) / kSlotParts);
+		st.slot_hi = st.slot_lo + b;
+		st.slot_lo += a;
+		nf = nf > a ? nf - a : 0u;
+	}
 	const uint32_t nsl = st.slot_hi - st.slot_lo;
 	// Every sweep over the stripe's slots takes groups of 8 consecutive slots per thread, read with one
 	// aligned 8-byte load per map (byte loads are processed lane by lane: sixteen of them per 8 slots

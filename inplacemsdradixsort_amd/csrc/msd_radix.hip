@@ -602,14 +602,14 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 		// ---- block metadata: child geometry, misplaced-block lists, holes
 		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(1024), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
-		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
+		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
 		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca);
 		{
 			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors);
 			if (rc) return rc;
 		}
-		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents,
+		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
 		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
 				   keys, vals, (K *)rb.xkeys, rb.xvals);
