@@ -823,7 +823,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 		}
 		__syncthreads(); // B1
 		// ---- per bucket: completed blocks take a consumed slot of the bucket's own piece if there is one
-		uint32_t pend_blocks = 0, own_r = 0;
+		uint32_t pend_blocks = 0, own_r = 0, sel_state = 0;
 		if (tid < kP) {
 			const uint32_t bs = bst[tid], fill0 = bs >> 18;
 			uint32_t q_r = (bs >> 16) & 3u;
@@ -849,7 +849,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 			meta[tid] = fill0 | (nb_r << 8) | (own << 20);
 			loff[tid] = wr; // first own destination (index into the piece) of this tile
 			own_r = own;
-			select_reads(wr + own, bs & 0xFFFFu, q_r, L_r - nb_r * B, &tmp[12 + par]);
+			sel_state = (bs & 0xFFFFu) | (q_r << 16) | ((L_r - nb_r * B) << 18); // reads issued | in flight | new fill
 		}
 		if (tid == 0) {
 			tmp[par ^ 1] = 0;
@@ -895,6 +895,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) v
 			}
 			__syncthreads(); // B2b
 		}
+		// the next reads are chosen after the barrier: the other twelve waves scatter meanwhile
+		// (the choice is needed only when the next tile's loads are issued, after B3)
+		if (tid < kP) select_reads(cw[tid] >> 16, sel_state & 0xFFFFu, (sel_state >> 16) & 3u, sel_state >> 18, &tmp[12 + par]);
 		const uint32_t nx = min(tmp[2 + par], (uint32_t)L::XT);
 		const uint32_t njobs = tmp[par];
 		// ---- scatter
