@@ -47,11 +47,11 @@ template <> struct Cfg<uint32_t, NoVal> {
 	static constexpr int SORT_TH = 1024, SORT_KPT = 24; // LDS sort capacity 24576
 };
 template <> struct Cfg<uint64_t, NoVal> {
-	static constexpr int B = 32, T = 4096, TH = 512;
+	static constexpr int B = 32, T = 4096, TH = 1024;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 12; // 12288
 };
 template <> struct Cfg<uint64_t, uint64_t> {
-	static constexpr int B = 32, T = 2048, TH = 256;
+	static constexpr int B = 32, T = 2048, TH = 1024;
 	static constexpr int SORT_TH = 1024, SORT_KPT = 6; // 6144
 };
 
@@ -206,7 +206,7 @@ template <typename K, typename V> struct ClassifyLds {
 };
 
 template <typename K, typename V>
-__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) void classify_kernel(
+__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<V>::value ? 4 : 8) : 1)) void classify_kernel(
 	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, uint8_t *__restrict__ block_map,
 	uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt, uint32_t *__restrict__ lo_off,
@@ -640,7 +640,7 @@ __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int 
 }
 
 template <typename K, typename V>
-__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? 8 : 1)) void classify_direct_kernel(
+__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<V>::value ? 4 : 8) : 1)) void classify_direct_kernel(
 	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plans, uint8_t *__restrict__ block_map,
 	uint8_t *__restrict__ slot_full, uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt,
