@@ -550,11 +550,10 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		// ---- A: classify (histogram falls out of it)
 		bool direct = false;
 		// Direct placement (DESIGN.md section 2, A'): the first round from a sample, later rounds -- only
-		// after a direct first round -- from exact counts (a read-only pass).  Tuples: measured slower than
-		// stripe-local classification + full permutation, so only when forced.
+		// after a direct first round -- from exact counts (a read-only pass).
 		// (the read schedule hands a bucket one slot per tile: with fewer than 256 buckets the tiles
 		// are not filled, so narrower digits keep the streaming kernel unless forced)
-		bool try_direct = (HV ? c->direct_mode == 2 : c->direct_mode != 0) && rp.round_keys >= c->direct_min;
+		bool try_direct = c->direct_mode != 0 && rp.round_keys >= c->direct_min;
 		for (size_t i = 0; i < np && try_direct; ++i) try_direct = rp.parents[i].width == 8 || c->direct_mode == 2;
 		if (try_direct && np > 1) {
 			try_direct = prev_direct && np <= kDirectMaxParents;
