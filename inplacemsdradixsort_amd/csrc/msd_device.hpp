@@ -97,7 +97,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t direct_uneven; // per round: parents whose children are too unequal for direct placement
 	uint32_t nslow;         // counting-sort segments the fast kernel left to count_walk_kernel
 	uint32_t count_ticket2; // work ticket of count_walk_kernel
-	uint32_t pad[3];
+	uint32_t nevict;        // per round: side-store blocks handed out for evictions
+	uint32_t pad[2];
 };
 
 // ---------------------------------------------------------------- utilities
@@ -1029,6 +1030,9 @@ struct ChildArrays {
 	uint64_t *list_len, *list_base;
 	uint32_t *rpos;   // claim cursor of the child's list
 	uint32_t *flags;  // bit0 evict, bit1 excess
+	uint32_t *rot;    // the chain-continuing entries [0, n_int) of the list are claimed from entry rot on, wrapping around
+	uint32_t *nev;    // blocks of this child's list parked in the side store (each opens a chain start)
+	uint32_t *xfirst; // first side-store block of those
 };
 
 template <int B>
@@ -1251,18 +1255,47 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	});
 }
 
+// A chain starts at a hole and ends at a chain-ending list entry; there are as many of one as of the
+// other, and that number is the parallelism of the block permutation.  Inputs whose stripes hold few
+// buckets (sorted, reversed, long runs) leave about one empty slot per stripe: a thousand chains of
+// thousands of steps each, one wave instruction at a time (measured: 100 ms instead of 1).  Below
+// kMinChains the lists therefore park more of their blocks in the side store -- every parked block ends
+// a chain and the slot it left starts one -- in proportion to their length.
+constexpr uint32_t kMinChains = 1u << 16;
+
 // Per child: list length, eviction / excess decisions.
-__global__ __launch_bounds__(256) void list_prepare_kernel(uint32_t nchildren, ChildArrays ca)
+__global__ __launch_bounds__(256) void list_prepare_kernel(uint32_t nchildren, ChildArrays ca, Counters *__restrict__ ctr,
+	uint32_t round_slots, uint32_t pool_cap)
 {
 	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
 	if (ci >= nchildren) return;
 	const uint32_t ni = ca.n_int[ci], nf = ca.n_fr[ci];
-	const uint32_t ev = (ni > 0 && nf == 0) ? 1u : 0u;
+	const uint32_t nholes = ctr->nholes; // complete: the counting pass is over
+	uint32_t ev = (ni > 0 && nf == 0) ? 1u : 0u; // a list without a chain-ending entry gets one (hole-free cycles)
+	if (nholes < kMinChains && ni > ev) {
+		const uint64_t want = ((uint64_t)(kMinChains - nholes) * (ni + nf) + round_slots - 1) / (round_slots ? round_slots : 1u);
+		ev = (uint32_t)(want + ev < ni ? want + ev : ni);
+	}
+	uint32_t first = 0;
+	if (ev) {
+		first = atomicAdd(&ctr->nevict, ev);
+		if (first + ev > pool_cap) { // (cannot happen: the pool holds kMinChains + one block per child)
+			atomicAdd(&ctr->errors, 1u);
+			ev = 0;
+		}
+	}
 	const uint32_t ex = ca.F[ci] > ca.I[ci] ? 2u : 0u;
 	ca.n_int0[ci] = ni;
 	ca.n_int[ci] = ni - ev; // entries [0, n_int) keep a chain going, the rest end it
+	ca.nev[ci] = ev;
+	ca.xfirst[ci] = first;
+	// Lists are ordered by slot and all lists are consumed at about the same pace: on locally sorted or
+	// run-structured inputs entry k of every list lies at the same offset inside its child's region, a
+	// whole number of child regions apart -- every access of the chip then agrees in the address bits that
+	// select the memory channel (measured: 12 x slower).  A per-child starting entry breaks the lockstep.
+	ca.rot[ci] = ni - ev ? (uint32_t)((ci * 2654435761u) ^ (ci >> 7) * 40503u) % (ni - ev) : 0u;
 	ca.list_len[ci] = ni + nf;
-	ca.flags[ci] = ev | ex;
+	ca.flags[ci] = (ev ? 1u : 0u) | ex;
 }
 
 // address of a block slot: real slots inside the key array, virtual ones in the side store
@@ -1272,9 +1305,11 @@ __device__ __forceinline__ T *slot_ptr(T *base, T *xbase, uint32_t slot)
 	return slot < kXBase ? base + (uint64_t)slot * B : xbase + (uint64_t)(slot - kXBase) * B;
 }
 
-// One thread per child; the rare child that needs it (a) evicts one interior-class block to
-// the side store so that its list ends with a chain-terminating entry, (b) opens the virtual
-// slot that takes its excess block.
+// One wave per child.  (a) The last nev chain-continuing entries of the child's list are parked in the
+// side store: the block is copied there, the entry now points at the copy and ends a chain, the slot it
+// left becomes a hole (owned by the interior it lies in).  (b) A child with more full blocks than
+// interior slots opens the virtual slot that takes its excess block.
+// Side store layout: block 2*ci+1 = child ci's excess block; blocks from 2*nchildren on = the eviction pool.
 template <typename K, typename V>
 __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArrays ca,
 	ListEntry *__restrict__ list, ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
@@ -1282,29 +1317,36 @@ __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArr
 {
 	constexpr int B = Cfg<K, V>::B;
 	constexpr bool HV = has_val<V>::value;
-	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+	constexpr int VEC = Vec16<K>::N;
+	constexpr int LPB = B / VEC; // lanes per block (16)
+	const uint32_t ci = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63;
 	if (ci >= nchildren) return;
 	const uint32_t fl = ca.flags[ci];
 	if (fl == 0) return;
 	if (fl & 1u) {
-		const uint64_t e = ca.list_base[ci] + ca.n_int0[ci] - 1;
-		const ListEntry ent = list[e];
-		const uint32_t xs = kXBase + 2 * ci;
-		K *dk = slot_ptr<K, B>(keys, xkeys, xs);
-		const K *sk = slot_ptr<K, B>(keys, xkeys, ent.slot);
-		for (int j = 0; j < B; ++j) dk[j] = sk[j];
-		if constexpr (HV) {
-			uint64_t *dv = slot_ptr<uint64_t, B>(vals, xvals, xs);
-			const uint64_t *sv = slot_ptr<uint64_t, B>(vals, xvals, ent.slot);
-			for (int j = 0; j < B; ++j) dv[j] = sv[j];
+		const uint32_t nev = ca.nev[ci], xf = ca.xfirst[ci];
+		const uint64_t e0 = ca.list_base[ci] + ca.n_int[ci]; // entries [n_int, n_int0) are parked
+		uint32_t hbase = 0;
+		if (lane == 0) hbase = atomicAdd(&ctr->nholes, nev);
+		hbase = __shfl(hbase, 0);
+		for (uint32_t j = lane / LPB; j < nev; j += 64 / LPB) {
+			const ListEntry ent = list[e0 + j];
+			const uint32_t xs = kXBase + 2 * nchildren + xf + j, sub = lane % LPB;
+			*reinterpret_cast<uint4 *>(slot_ptr<K, B>(keys, xkeys, xs) + sub * VEC) =
+				*reinterpret_cast<const uint4 *>(slot_ptr<K, B>(keys, xkeys, ent.slot) + sub * VEC);
+			if constexpr (HV)
+				*reinterpret_cast<uint4 *>(slot_ptr<uint64_t, B>(vals, xvals, xs) + sub * VEC) =
+					*reinterpret_cast<const uint4 *>(slot_ptr<uint64_t, B>(vals, xvals, ent.slot) + sub * VEC);
+			if (sub == 0) {
+				ListEntry ne;
+				ne.slot = xs;
+				ne.owner = kNoOwner;
+				list[e0 + j] = ne;
+				holes[hbase + j] = ent; // the vacated slot, owned by the interior it lies in
+			}
 		}
-		ListEntry ne;
-		ne.slot = xs;
-		ne.owner = kNoOwner;
-		list[e] = ne;
-		holes[atomicAdd(&ctr->nholes, 1u)] = ent; // the vacated slot, owned by the interior it lies in
 	}
-	if (fl & 2u) {
+	if ((fl & 2u) && lane == 0) {
 		ListEntry hsl;
 		hsl.slot = kXBase + 2 * ci + 1;
 		hsl.owner = ci;
@@ -1394,10 +1436,16 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 				atomicAdd(&ctr->errors, 1u);
 				active = false;
 			} else {
-				const ListEntry e = list[(uint32_t)ca.list_base[owner] + idx];
+				const uint32_t ni = ca.n_int[owner];
+				last = idx >= ni;
+				uint32_t at = idx;
+				if (!last) { // chain-continuing entries: rotated order
+					at += ca.rot[owner];
+					if (at >= ni) at -= ni;
+				}
+				const ListEntry e = list[(uint32_t)ca.list_base[owner] + at];
 				src = e.slot;
 				src_owner = e.owner;
-				last = idx >= ca.n_int[owner];
 			}
 		}
 		const uint64_t mv = __ballot(active);

@@ -334,12 +334,17 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 	rb.ca.list_base = b.take<uint64_t>(nc);
 	rb.ca.rpos = b.take<uint32_t>((size_t)nc * kRposStride);
 	rb.ca.flags = b.take<uint32_t>(nc);
+	rb.ca.rot = b.take<uint32_t>(nc);
+	rb.ca.nev = b.take<uint32_t>(nc);
+	rb.ca.xfirst = b.take<uint32_t>(nc);
 	rb.list = b.take<ListEntry>(rp.nslots + 1);
 	// holes: tail slots (< kP + 2 per stripe) + one eviction + one excess per child
-	const uint64_t hmax = std::min<uint64_t>(rp.nslots, (uint64_t)ns * (kP + 2)) + 2ull * nc + 1;
+	// + the eviction pool: at most one parked block per child plus what it takes to reach kMinChains chains
+	const uint64_t pool = (uint64_t)nc + kMinChains;
+	const uint64_t hmax = std::min<uint64_t>(rp.nslots, (uint64_t)ns * (kP + 2)) + 2ull * nc + pool + 1;
 	rb.holes = b.take<ListEntry>(hmax);
-	rb.xkeys = b.take<K>((size_t)2 * nc * C::B);
-	rb.xvals = HV ? b.take<uint64_t>((size_t)2 * nc * C::B) : nullptr;
+	rb.xkeys = b.take<K>((size_t)(2 * nc + pool) * C::B);
+	rb.xvals = HV ? b.take<uint64_t>((size_t)(2 * nc + pool) * C::B) : nullptr;
 	const size_t ntiles = (nc + kScanTile - 1) / kScanTile + 1;
 	rb.scan_state = b.take<unsigned long long>(ntiles);
 	rb.scan_ctr = b.take<uint32_t>(4);
@@ -533,7 +538,10 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			small_count = c->lists + 3 * c->lists_cap;
 		}
 		const uint32_t small_cap = (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu);
-		if (round > 0) HIPCHK(c, hipMemsetAsync(ctr, 0, 3 * sizeof(uint32_t), c->stream)); // nholes, hole_cursor, next_parents
+		if (round > 0) {
+			HIPCHK(c, hipMemsetAsync(ctr, 0, 3 * sizeof(uint32_t), c->stream)); // nholes, hole_cursor, next_parents
+			HIPCHK(c, hipMemsetAsync(&ctr->nevict, 0, sizeof(uint32_t), c->stream));
+		}
 		// ---- upload tables
 		{
 			const size_t bytes = np * sizeof(Parent) + ns * sizeof(Stripe);
@@ -603,14 +611,15 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(1024), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
 		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
-		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca);
+		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr,
+				   (uint32_t)std::min<uint64_t>(rp.nslots, 0xFFFFFFFFu), (uint32_t)(nc + kMinChains));
 		{
 			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors);
 			if (rc) return rc;
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
-		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
+		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((nc + 3) / 4), dim3(256), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
 				   keys, vals, (K *)rb.xkeys, rb.xvals);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "B metadata");
