@@ -493,6 +493,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 struct DirectPlan {
 	uint32_t est_cnt[kP];   // sampled digit counts
 	uint32_t bound[kP + 1]; // estimated child boundaries in slots (bound[0] = first slot of the parent)
+	// neighbouring keys compared / found with equal digits: sorted, reversed or run-structured input (a
+	// workgroup then reads one bucket at a time and nothing finds a slot in its own piece)
+	uint32_t adj_seen, adj_same;
 };
 
 template <typename K>
@@ -503,6 +506,7 @@ __global__ __launch_bounds__(256) void direct_sample_kernel(const K *__restrict_
 	const Parent pa = parents[0];
 	const uint32_t mask = (1u << pa.width) - 1u;
 	h[threadIdx.x] = 0;
+	uint32_t seen = 0, same = 0; // per wave (identical in all its lanes)
 	__syncthreads();
 	// every `every`-th run of 256 consecutive keys (coalesced), four runs in flight per thread
 	const uint64_t nruns = pa.count / 256;
@@ -513,11 +517,23 @@ __global__ __launch_bounds__(256) void direct_sample_kernel(const K *__restrict_
 		for (int u = 0; u < 4; ++u)
 			if (r + u * step < nruns) k4[u] = keys[pa.start + (r + u * step) * 256 + threadIdx.x];
 #pragma unroll
-		for (int u = 0; u < 4; ++u)
-			if (r + u * step < nruns) atomicAdd(&h[digit_of(k4[u], pa.shift, mask)], 1u);
+		for (int u = 0; u < 4; ++u) {
+			if (r + u * step < nruns) { // (uniform)
+				const uint32_t d = digit_of(k4[u], pa.shift, mask);
+				atomicAdd(&h[d], 1u);
+				if (u == 0 && (blockIdx.x & 7u) == 0) { // (a small part of the sample is plenty)
+					same += __popcll(__ballot(d == (uint32_t)__shfl_down((int)d, 1) && (threadIdx.x & 63) != 63));
+					seen += 63;
+				}
+			}
+		}
 	}
 	__syncthreads();
 	if (h[threadIdx.x]) atomicAdd(&plan->est_cnt[threadIdx.x], h[threadIdx.x]);
+	if ((threadIdx.x & 63) == 0 && seen) {
+		atomicAdd(&plan->adj_seen, seen);
+		atomicAdd(&plan->adj_same, same);
+	}
 }
 
 // Exact digit counts per parent for the rounds after the first (a sample will not do there: the
@@ -534,6 +550,7 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 	const Parent pa = parents[st.parent];
 	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u, tid = threadIdx.x;
 	if (tid < kP) h[tid] = 0;
+	uint32_t seen = 0, same = 0;
 	__syncthreads();
 	const uint64_t a0 = (st.begin + VEC - 1) / VEC * VEC, a1 = st.end / VEC * VEC; // 16-byte aligned part
 	if (a0 < a1) {
@@ -559,6 +576,8 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 				if (v + (uint64_t)u * 1024 < nvec) {
 #pragma unroll
 					for (int e = 0; e < VEC; ++e) atomicAdd(&h[digit_of(kk[u][e], shift, mask)], 1u);
+					seen += 1;
+					same += digit_of(kk[u][0], shift, mask) == digit_of(kk[u][VEC - 1], shift, mask) ? 1u : 0u;
 				}
 			}
 		}
@@ -567,6 +586,16 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 		for (uint64_t i = st.begin + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
 	__syncthreads();
 	if (tid < kP && h[tid]) atomicAdd(&plans[st.parent].est_cnt[tid], h[tid]);
+	// first and last key of every 16-byte vector: equal digits nearly always <=> locally sorted / runs
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		seen += (uint32_t)__shfl_xor((int)seen, o);
+		same += (uint32_t)__shfl_xor((int)same, o);
+	}
+	if ((tid & 63) == 0 && seen) {
+		atomicAdd(&plans[st.parent].adj_seen, seen);
+		atomicAdd(&plans[st.parent].adj_same, same);
+	}
 }
 
 // One workgroup per parent: counts (sampled or exact) -> child boundaries on the slot grid; a parent
@@ -596,7 +625,9 @@ __global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restri
 		atomicMax(&s_mx, (uint32_t)c);
 	}
 	__syncthreads();
-	if (d == 0 && !(s_mn > 0 && (double)s_mx <= 1.25 * (double)s_mn)) atomicAdd(&ctr->direct_uneven, 1u);
+	// (equal neighbours: 1/256 of the pairs on random keys; an eighth of them means runs)
+	const bool runs = (uint64_t)plan->adj_same * 8u > plan->adj_seen;
+	if (d == 0 && (runs || !(s_mn > 0 && (double)s_mx <= 1.25 * (double)s_mn))) atomicAdd(&ctr->direct_uneven, 1u);
 }
 
 template <typename K, typename V> struct DirectLds {
