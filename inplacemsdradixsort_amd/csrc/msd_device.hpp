@@ -1344,23 +1344,28 @@ __device__ __forceinline__ T *slot_ptr(T *base, T *xbase, uint32_t slot)
 template <typename K, typename V>
 __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArrays ca,
 	ListEntry *__restrict__ list, ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
-	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals)
+	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals,
+	uint32_t waves_per_child)
 {
 	constexpr int B = Cfg<K, V>::B;
 	constexpr bool HV = has_val<V>::value;
 	constexpr int VEC = Vec16<K>::N;
 	constexpr int LPB = B / VEC; // lanes per block (16)
-	const uint32_t ci = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63;
+	// waves_per_child waves share a child (few children with many blocks to park: low-cardinality keys)
+	const uint32_t wid = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63;
+	const uint32_t ci = wid / waves_per_child, part = wid % waves_per_child;
 	if (ci >= nchildren) return;
 	const uint32_t fl = ca.flags[ci];
 	if (fl == 0) return;
 	if (fl & 1u) {
 		const uint32_t nev = ca.nev[ci], xf = ca.xfirst[ci];
 		const uint64_t e0 = ca.list_base[ci] + ca.n_int[ci]; // entries [n_int, n_int0) are parked
+		// this wave's share [j0, j1) of the parked entries; its holes go to a range of their own
+		const uint32_t j0 = (uint32_t)((uint64_t)nev * part / waves_per_child), j1 = (uint32_t)((uint64_t)nev * (part + 1) / waves_per_child);
 		uint32_t hbase = 0;
-		if (lane == 0) hbase = atomicAdd(&ctr->nholes, nev);
-		hbase = __shfl(hbase, 0);
-		for (uint32_t j = lane / LPB; j < nev; j += 64 / LPB) {
+		if (lane == 0 && j1 > j0) hbase = atomicAdd(&ctr->nholes, j1 - j0);
+		hbase = __shfl(hbase, 0) - j0;
+		for (uint32_t j = j0 + lane / LPB; j < j1; j += 64 / LPB) {
 			const ListEntry ent = list[e0 + j];
 			const uint32_t xs = kXBase + 2 * nchildren + xf + j, sub = lane % LPB;
 			*reinterpret_cast<uint4 *>(slot_ptr<K, B>(keys, xkeys, xs) + sub * VEC) =
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArr
 			}
 		}
 	}
-	if ((fl & 2u) && lane == 0) {
+	if ((fl & 2u) && lane == 0 && part == 0) {
 		ListEntry hsl;
 		hsl.slot = kXBase + 2 * ci + 1;
 		hsl.owner = ci;

@@ -619,8 +619,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
-		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((nc + 3) / 4), dim3(256), 0, c->stream, nc, rb.ca, rb.list, rb.holes, ctr,
-				   keys, vals, (K *)rb.xkeys, rb.xvals);
+		const uint32_t evict_waves = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, 16384 / nc)); // per child
+		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((unsigned)(((uint64_t)nc * evict_waves + 3) / 4)), dim3(256), 0, c->stream, nc, rb.ca,
+				   rb.list, rb.holes, ctr, keys, vals, (K *)rb.xkeys, rb.xvals, evict_waves);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "B metadata");
 

@@ -19,7 +19,17 @@ shapes = {
     "runs64k": lambda: (base & 0x00FFFFFF) | (((torch.arange(n, device="cuda", dtype=torch.int64) >> 16) & 0xFF) << 24).to(torch.int32),
     # sorted within blocks of 2^20, blocks shuffled (locally sorted data)
     "blocksorted": lambda: base.view(-1, 1 << 20).sort(dim=1).values.contiguous().view(-1),
+    "const": lambda: torch.full_like(base, 0x12345678),
+    "two": lambda: torch.where((base & 1) == 0, torch.full_like(base, 7), torch.full_like(base, -9)),
+    "few16": lambda: (base & 0xF) * 0x01010101,
+    "low8": lambda: base & 0xFF,
+    "high8": lambda: base & (-0x1000000),
+    "heavy50": lambda: torch.where((base & 1) == 0, torch.full_like(base, 0x5A5A5A5A), base),
+    "mid16": lambda: base & 0x00FFFF00,
 }
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+if only:
+    shapes = {k: v for k, v in shapes.items() if k in only}
 for name, mk in shapes.items():
     for rep in range(2):
         t = mk()
