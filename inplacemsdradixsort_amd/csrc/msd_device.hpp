@@ -2126,6 +2126,7 @@ __global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict
 	const uint32_t half = nv > 32768u ? 32768u : nv;
 	const K *src = keys + sg.start + ch.off;
 	uint32_t *gh = ghist + (size_t)ch.seg * 65536;
+	bool hot = false; // (wave-uniform)
 	for (uint32_t base = 0; base < nv; base += half) {
 		for (uint32_t j = tid; j < half; j += 1024) cw[j] = 0;
 		__syncthreads();
@@ -2140,7 +2141,29 @@ __global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict
 			for (int u = 0; u < 4; ++u) {
 				const uint32_t idx = i0 + u * 1024 + tid;
 				const uint32_t v = ((uint32_t)k4[u] & mask) - base;
-				if (idx < ch.len && v < half) atomicAdd(&cw[v], 1u);
+				bool mine = idx < ch.len && v < half;
+				if (hot) {
+					// heavily repeated values (low-cardinality keys): lanes that share a value take ONE
+					// fetch-add together -- a same-address LDS atomic serialises per lane.  Tried only
+					// while the previous batch found such a value.
+					hot = false;
+#pragma unroll
+					for (int r = 0; r < 4; ++r) {
+						const uint64_t todo = __ballot(mine);
+						if (!todo) break;
+						const int l = __ffsll((long long)todo) - 1;
+						const uint32_t vl = (uint32_t)__shfl((int)v, l);
+						const uint64_t same = __ballot(mine && v == vl);
+						if (__popcll(same) < 8) break;
+						if ((int)(tid & 63) == l) atomicAdd(&cw[vl], (uint32_t)__popcll(same));
+						if (v == vl) mine = false;
+						hot = true;
+					}
+				} else if (u == 0) { // probe: does the first lane's value repeat in this wave?
+					const uint32_t vl = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+					hot = __popcll(__ballot(mine && v == vl)) >= 8;
+				}
+				if (mine) atomicAdd(&cw[v], 1u);
 			}
 		}
 		__syncthreads();
