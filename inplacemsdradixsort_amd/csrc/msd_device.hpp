@@ -1351,6 +1351,41 @@ __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArr
 	constexpr bool HV = has_val<V>::value;
 	constexpr int VEC = Vec16<K>::N;
 	constexpr int LPB = B / VEC; // lanes per block (16)
+	if (waves_per_child == 0) { // many children, next to nothing to do for any of them: one thread per child
+		const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+		if (ci >= nchildren) return;
+		const uint32_t fl = ca.flags[ci];
+		if (fl == 0) return;
+		if (fl & 1u) {
+			const uint32_t nev = ca.nev[ci], xf = ca.xfirst[ci];
+			const uint64_t e0 = ca.list_base[ci] + ca.n_int[ci];
+			const uint32_t hbase = atomicAdd(&ctr->nholes, nev);
+			for (uint32_t j = 0; j < nev; ++j) {
+				const ListEntry ent = list[e0 + j];
+				const uint32_t xs = kXBase + 2 * nchildren + xf + j;
+				K *dk = slot_ptr<K, B>(keys, xkeys, xs);
+				const K *sk = slot_ptr<K, B>(keys, xkeys, ent.slot);
+				for (int e = 0; e < B; ++e) dk[e] = sk[e];
+				if constexpr (HV) {
+					uint64_t *dv = slot_ptr<uint64_t, B>(vals, xvals, xs);
+					const uint64_t *sv = slot_ptr<uint64_t, B>(vals, xvals, ent.slot);
+					for (int e = 0; e < B; ++e) dv[e] = sv[e];
+				}
+				ListEntry ne;
+				ne.slot = xs;
+				ne.owner = kNoOwner;
+				list[e0 + j] = ne;
+				holes[hbase + j] = ent;
+			}
+		}
+		if (fl & 2u) {
+			ListEntry hsl;
+			hsl.slot = kXBase + 2 * ci + 1;
+			hsl.owner = ci;
+			holes[atomicAdd(&ctr->nholes, 1u)] = hsl;
+		}
+		return;
+	}
 	// waves_per_child waves share a child (few children with many blocks to park: low-cardinality keys)
 	const uint32_t wid = blockIdx.x * 4 + threadIdx.x / 64, lane = threadIdx.x & 63;
 	const uint32_t ci = wid / waves_per_child, part = wid % waves_per_child;
@@ -1984,7 +2019,10 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 		s_or[1] = ~(K)0;
 		wtot[16] = 0;
 	}
-	for (uint32_t j = tid; j < ((uint32_t)1 << kLeafCountBits) / 2; j += TH) cw[j] = 0;
+	// (measured: fewer counters for small segments make the kernel slower -- more equal-prefix groups to fix up)
+	const uint32_t cbits = (uint32_t)kLeafCountBits;
+	const uint32_t nwords = (1u << cbits) / 2; // 2 x 16-bit counters per word
+	for (uint32_t j = tid; j < nwords; j += TH) cw[j] = 0;
 	__syncthreads();
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
@@ -2005,7 +2043,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 	const K vopen = (s_or[0] ^ s_or[1]) & openmask;
 	if (vopen == 0) return; // constant on the open bits: already sorted
 	const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
-	const uint32_t shift = nbits > (uint32_t)kLeafCountBits ? nbits - kLeafCountBits : 0;
+	const uint32_t shift = nbits > cbits ? nbits - cbits : 0;
 	const uint32_t mask = (1u << (nbits - shift)) - 1u;
 	uint32_t rk[KPT];
 #pragma unroll
@@ -2017,27 +2055,28 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 		}
 	}
 	__syncthreads();
-	// counts -> exclusive positions, in place; thread t owns 8 words
-	constexpr uint32_t WPT = (((uint32_t)1 << kLeafCountBits) / 2) / TH;
-	static_assert(WPT >= 1, "counter words per thread");
-	const uint32_t w0 = tid * WPT;
+	// counts -> exclusive positions, in place; thread t owns wpt consecutive words
+	const uint32_t wpt = nwords >= (uint32_t)TH ? nwords / TH : 1u;
+	const uint32_t w0 = tid * wpt;
 	uint32_t tot = 0;
-#pragma unroll
-	for (uint32_t j = 0; j < WPT; ++j) {
-		const uint32_t x = cw[w0 + j];
-		tot += (x & 0xFFFFu) + (x >> 16);
+	if (w0 < nwords) {
+		for (uint32_t j = 0; j < wpt; ++j) {
+			const uint32_t x = cw[w0 + j];
+			tot += (x & 0xFFFFu) + (x >> 16);
+		}
 	}
 	const uint32_t inc = wave_incl_scan(tot);
 	if (lane == 63) wtot[w] = inc;
 	__syncthreads();
 	uint32_t run = inc - tot;
 	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
-#pragma unroll
-	for (uint32_t j = 0; j < WPT; ++j) {
-		const uint32_t x = cw[w0 + j];
-		const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
-		cw[w0 + j] = run | ((run + lo) << 16);
-		run += lo + hi;
+	if (w0 < nwords) {
+		for (uint32_t j = 0; j < wpt; ++j) {
+			const uint32_t x = cw[w0 + j];
+			const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
+			cw[w0 + j] = run | ((run + lo) << 16);
+			run += lo + hi;
+		}
 	}
 	__syncthreads();
 #pragma unroll

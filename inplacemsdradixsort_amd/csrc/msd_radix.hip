@@ -619,8 +619,10 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
-		const uint32_t evict_waves = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, 16384 / nc)); // per child
-		hipLaunchKernelGGL((evict_kernel<K, V>), dim3((unsigned)(((uint64_t)nc * evict_waves + 3) / 4)), dim3(256), 0, c->stream, nc, rb.ca,
+		// per child: up to 64 waves when there are few children, one thread when there are very many
+		const uint32_t evict_waves = nc > 16384 ? 0u : (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, 16384 / nc));
+		const unsigned evict_grid = evict_waves ? (unsigned)(((uint64_t)nc * evict_waves + 3) / 4) : (unsigned)((nc + 255) / 256);
+		hipLaunchKernelGGL((evict_kernel<K, V>), dim3(evict_grid), dim3(256), 0, c->stream, nc, rb.ca,
 				   rb.list, rb.holes, ctr, keys, vals, (K *)rb.xkeys, rb.xvals, evict_waves);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "B metadata");
