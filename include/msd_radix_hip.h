@@ -37,7 +37,7 @@ enum {
 
 /* Create a sorting context on `device`; `stream` is a hipStream_t (NULL = the
  * default stream).  The context owns the auxiliary workspace (block map, block
- * lists, stripe leftovers; about 9 % of the data size at 2^30 u32 keys, grown on
+ * lists, stripe leftovers; about 12 % of the data size at 2^30 u32 keys, grown on
  * demand and reused between calls). */
 int msd_create(msd_ctx **ctx, int device, void *stream);
 int msd_destroy(msd_ctx *ctx);
