@@ -555,25 +555,25 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 	const uint64_t a0 = (st.begin + VEC - 1) / VEC * VEC, a1 = st.end / VEC * VEC; // 16-byte aligned part
 	if (a0 < a1) {
 		for (uint64_t i = st.begin + tid; i < a0; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
-		const uint64_t nvec = (a1 - a0) / VEC;
-		for (uint64_t v = tid; v < nvec; v += 4 * 1024) {
-			K kk[4][VEC];
+		const uint32_t nvec = (uint32_t)((a1 - a0) / VEC); // (a stripe has at most 2^20 elements)
+		const K *kp = keys + a0;                           // uniform base, 32-bit offsets, loads branch-free
+		constexpr int U = 8;
+		for (uint32_t v = tid; v < nvec; v += U * 1024) {
+			K kk[U][VEC];
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint64_t vv = v + (uint64_t)u * 1024;
-				if (vv < nvec) {
-					if constexpr (sizeof(K) == 4) {
-						const uint4 q = *reinterpret_cast<const uint4 *>(keys + a0 + vv * VEC);
-						kk[u][0] = q.x; kk[u][1] = q.y; kk[u][2] = q.z; kk[u][3] = q.w;
-					} else {
-						const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + a0 + vv * VEC);
-						kk[u][0] = q.x; kk[u][1] = q.y;
-					}
+			for (int u = 0; u < U; ++u) {
+				const uint32_t vv = min(v + (uint32_t)u * 1024u, nvec - 1u);
+				if constexpr (sizeof(K) == 4) {
+					const uint4 q = *reinterpret_cast<const uint4 *>(kp + (size_t)vv * VEC);
+					kk[u][0] = q.x; kk[u][1] = q.y; kk[u][2] = q.z; kk[u][3] = q.w;
+				} else {
+					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)vv * VEC);
+					kk[u][0] = q.x; kk[u][1] = q.y;
 				}
 			}
 #pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				if (v + (uint64_t)u * 1024 < nvec) {
+			for (int u = 0; u < U; ++u) {
+				if (v + (uint32_t)u * 1024u < nvec) {
 #pragma unroll
 					for (int e = 0; e < VEC; ++e) atomicAdd(&h[digit_of(kk[u][e], shift, mask)], 1u);
 					seen += 1;
