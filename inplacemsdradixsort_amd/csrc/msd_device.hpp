@@ -1310,7 +1310,7 @@ __global__ __launch_bounds__(256) void list_prepare_kernel(uint32_t nchildren, C
 	uint32_t first = 0;
 	if (ev) {
 		first = atomicAdd(&ctr->nevict, ev);
-		if (first + ev > pool_cap) { // (cannot happen: the pool holds kMinChains + one block per child)
+		if (first + ev > pool_cap) { // (cannot happen: the pool holds kMinChains + two blocks per child)
 			atomicAdd(&ctr->errors, 1u);
 			ev = 0;
 		}

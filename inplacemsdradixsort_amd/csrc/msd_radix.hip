@@ -339,8 +339,9 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 	rb.ca.xfirst = b.take<uint32_t>(nc);
 	rb.list = b.take<ListEntry>(rp.nslots + 1);
 	// holes: tail slots (< kP + 2 per stripe) + one eviction + one excess per child
-	// + the eviction pool: at most one parked block per child plus what it takes to reach kMinChains chains
-	const uint64_t pool = (uint64_t)nc + kMinChains;
+	// + the eviction pool: what it takes to reach kMinChains chains (shared out in proportion to the list
+	// lengths, rounded up per child) plus the one parked block a list without a chain-ending entry needs
+	const uint64_t pool = 2ull * nc + kMinChains;
 	const uint64_t hmax = std::min<uint64_t>(rp.nslots, (uint64_t)ns * (kP + 2)) + 2ull * nc + pool + 1;
 	rb.holes = b.take<ListEntry>(hmax);
 	rb.xkeys = b.take<K>((size_t)(2 * nc + pool) * C::B);
@@ -567,6 +568,11 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			try_direct = prev_direct && np <= kDirectMaxParents;
 			for (size_t i = 0; i < np && try_direct; ++i) try_direct = rp.parents[i].count >= c->direct_min_parent;
 		}
+		// A workgroup of a direct round reads its pieces, not its stripe: up to one slot per bucket more than
+		// the stripe holds.  Its leftovers (< B per bucket + head/tail) must fit the stripe's leftover area,
+		// which is capped by the stripe's own size: no direct placement for stripes smaller than that bound.
+		for (size_t i = 0; i < ns && try_direct; ++i)
+			try_direct = rp.stripes[i].end - rp.stripes[i].begin >= (((uint64_t)1 << rp.parents[rp.stripes[i].parent].width) * (B - 1) + 2 * B);
 		uint64_t max_piece = 0; // a piece is at most one stripe's share of its parent's slots; the kernel counts it in 16 bits
 		for (size_t i = 0; i < np && try_direct; ++i)
 			max_piece = std::max<uint64_t>(max_piece, rp.parents[i].count / B / (rp.parents[i].stripe_hi - rp.parents[i].stripe_lo) + 2);
@@ -612,7 +618,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
 				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
 		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr,
-				   (uint32_t)std::min<uint64_t>(rp.nslots, 0xFFFFFFFFu), (uint32_t)(nc + kMinChains));
+				   (uint32_t)std::min<uint64_t>(rp.nslots, 0xFFFFFFFFu), (uint32_t)(2 * nc + kMinChains));
 		{
 			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors);
 			if (rc) return rc;

@@ -163,6 +163,25 @@ def test_direct_one_digit_partition(dctx):
     assert (np.sort(out) == np.sort(k)).all()
 
 
+def test_direct_forced_on_heavy_duplicates_deep_recursion(dctx):
+    """Tuples with one value on 40 % of the keys, direct placement forced down to tiny parents: the heavy value's
+    segment goes through all eight digits.  (A round whose stripes are smaller than the leftover bound must
+    stream: a direct workgroup reads up to a slot per bucket more than its stripe holds -- found by tools/soak.py.)"""
+    dctx.set_option("direct_mode", 2)
+    dctx.set_option("direct_min", 1 << 14)
+    dctx.set_option("direct_min_parent", 1 << 10)
+    rng = np.random.default_rng(314)
+    n = 5592250
+    k = rng.integers(0, (1 << 64) - 1, n, dtype=np.uint64, endpoint=True)
+    k[rng.random(n) < 0.4] = k[0]
+    r = np.arange(n, dtype=np.uint64)
+    t, tr = dev(k), dev(r)
+    dctx.sort_pairs_u64(t, tr)
+    ko, ro = host(t), host(tr)
+    assert (ko == np.sort(k)).all()
+    assert (k[ro] == ko).all() and (np.sort(ro) == r).all()
+
+
 def test_direct_unaligned_start_and_odd_length(dctx):
     rng = np.random.default_rng(99)
     for off, n in [(4, (1 << 22) + 1), (8, (1 << 22) - 63), (12, (1 << 20) + 64)]:
