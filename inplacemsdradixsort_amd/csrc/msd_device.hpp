@@ -1436,13 +1436,17 @@ __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArr
 template <typename K, typename V>
 __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListEntry *__restrict__ list,
 	const ListEntry *__restrict__ holes, Counters *__restrict__ ctr,
-	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals)
+	K *__restrict__ keys, uint64_t *__restrict__ vals, K *__restrict__ xkeys, uint64_t *__restrict__ xvals,
+	uint32_t real_slots, uint32_t side_slots)
 {
 	constexpr int B = Cfg<K, V>::B;
 	constexpr bool HV = has_val<V>::value;
 	constexpr int VEC = Vec16<K>::N;
 	constexpr int LPB = B / VEC;      // lanes per block (16)
 	constexpr int BPI = 64 / LPB;     // blocks per wave instruction (4)
+	// a slot id from the lists is an address: refuse what lies outside the array / the side store
+	// (corrupted metadata must end in an error code, never in a stray 256-byte write)
+	auto slot_ok = [&](uint32_t s) { return s < kXBase ? s < real_slots : s - kXBase < side_slots; };
 	constexpr int NI = 64 / BPI;      // instructions to move 64 blocks (16)
 	constexpr int GROUPS = 4;         // shared claims are formed for the 4 most common buckets
 	const uint32_t lane = lane_id();
@@ -1517,6 +1521,10 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 				const ListEntry e = list[(uint32_t)ca.list_base[owner] + at];
 				src = e.slot;
 				src_owner = e.owner;
+				if (!slot_ok(src) || !slot_ok(hole)) {
+					atomicAdd(&ctr->errors, 1u);
+					active = false;
+				}
 			}
 		}
 		const uint64_t mv = __ballot(active);

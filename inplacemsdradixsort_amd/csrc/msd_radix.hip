@@ -637,7 +637,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		{
 			const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, std::max<uint64_t>(1, (rp.nslots + 255) / 256));
 			hipLaunchKernelGGL((chains_kernel<K, V>), dim3(grid), dim3(256), 0, c->stream, rb.ca, rb.list, rb.holes, ctr,
-					   keys, vals, (K *)rb.xkeys, rb.xvals);
+					   keys, vals, (K *)rb.xkeys, rb.xvals, (uint32_t)(n / B), (uint32_t)(4 * nc + kMinChains));
 			hipLaunchKernelGGL(chains_verify_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr);
 			HIPCHK(c, hipGetLastError());
 		}
