@@ -53,6 +53,15 @@ for c in range(cases):
     ctx.set_option("direct_min", 1 << int(torch.randint(14, 27, (1,)).item()))
     ctx.set_option("direct_min_parent", 1 << int(torch.randint(10, 18, (1,)).item()))
     x = make(kind, n, bits)
+    # sometimes: fewer open bits (end_bit) and a 16-byte aligned sub-array start
+    eb = bits
+    if int(torch.randint(0, 4, (1,)).item()) == 0:
+        eb = int(torch.randint(1, bits + 1, (1,)).item())
+        if eb < bits:
+            x = (x & ((1 << eb) - 1)) | (int(rnd(1, bits)[0].item()) & ~((1 << eb) - 1) & ((1 << bits) - 1) if bits == 32 else (x[0] & ~((1 << eb) - 1)))
+    off = int(torch.randint(0, 4, (1,)).item()) * (4 if bits == 32 else 2) if int(torch.randint(0, 3, (1,)).item()) == 0 else 0
+    if off:
+        x = torch.cat([rnd(off, bits), x])
     print(f"case {c}: {typ} n={n} kind={kind} mode={mode}", file=sys.stderr, flush=True) if os.environ.get("SOAK_VERBOSE") else None
     if bits == 64:
         # torch has no uint64 sort: order by (high, low) halves as unsigned via bias
@@ -61,21 +70,27 @@ for c in range(cases):
     else:
         ref = torch.sort(x).values
         k = x.to(torch.int32) if False else (x - ((x >> 31) << 32)).to(torch.int32)
+    if off:  # the head must stay untouched, the tail sorted
+        if bits == 64:
+            ref = torch.cat([x[:off], torch.sort(x[off:] ^ (-(1 << 63))).values ^ (-(1 << 63))])
+        else:
+            ref = torch.cat([x[:off], torch.sort(x[off:]).values])
     if typ == "u32":
-        ctx.sort_u32(k)
+        ctx.sort_u32(k[off:], end_bit=eb)
         out = k.to(torch.int64) & 0xFFFFFFFF
         ok = bool((out == ref).all())
     elif typ == "u64":
-        ctx.sort_u64(k)
+        ctx.sort_u64(k[off:], end_bit=eb)
         ok = bool((k == ref).all())
     else:
-        r = torch.arange(n, device="cuda", dtype=torch.int64)
-        ctx.sort_pairs_u64(k, r)
+        r = torch.arange(n + off, device="cuda", dtype=torch.int64)
+        ctx.sort_pairs_u64(k[off:], r[off:], end_bit=eb)
+        n = n + off
         # (check the rids' range first: indexing with a corrupted rid would fault inside torch)
         ok = bool(((r >= 0) & (r < n)).all()) and bool((torch.sort(r).values == torch.arange(n, device="cuda")).all())
         ok = ok and bool((k == ref).all()) and bool((x[r] == k).all())
     if not ok:
-        print(f"FAIL case {c}: typ={typ} n={n} kind={kind} mode={mode}", ctx.stats(), flush=True)
+        print(f"FAIL case {c}: typ={typ} n={n} kind={kind} mode={mode} end_bit={eb} off={off}", ctx.stats(), flush=True)
         sys.exit(1)
     if c % 20 == 0:
         print(f"case {c} ok ({typ} n={n} kind={kind} mode={mode}) t={time.time()-t_start:.0f}s", flush=True)
