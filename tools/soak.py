@@ -45,13 +45,15 @@ t_start = time.time()
 for c in range(cases):
     typ = types[c % len(types)]
     bits = 32 if typ == "u32" else 64
-    logn = float(torch.empty(1).uniform_(8, 27.3 if typ != "pairs" else 26.3).item())
+    lo_, hi_ = float(os.environ.get("SOAK_LOGN_MIN", 8)), float(os.environ.get("SOAK_LOGN_MAX", 27.3))
+    logn = float(torch.empty(1).uniform_(lo_, hi_ if typ != "pairs" else hi_ - 1).item())
     n = int(2 ** logn) + int(torch.randint(0, 5, (1,)).item())
     kind = int(torch.randint(0, 9, (1,)).item())
     mode = int(torch.randint(0, 3, (1,)).item())
     ctx.set_option("direct_mode", mode)
-    ctx.set_option("direct_min", 1 << int(torch.randint(14, 27, (1,)).item()))
-    ctx.set_option("direct_min_parent", 1 << int(torch.randint(10, 18, (1,)).item()))
+    if not os.environ.get("SOAK_DEFAULT_OPTS"):
+        ctx.set_option("direct_min", 1 << int(torch.randint(14, 27, (1,)).item()))
+        ctx.set_option("direct_min_parent", 1 << int(torch.randint(10, 18, (1,)).item()))
     x = make(kind, n, bits)
     # sometimes: fewer open bits (end_bit) and a 16-byte aligned sub-array start
     eb = bits
@@ -92,6 +94,7 @@ for c in range(cases):
     if not ok:
         print(f"FAIL case {c}: typ={typ} n={n} kind={kind} mode={mode} end_bit={eb} off={off}", ctx.stats(), flush=True)
         sys.exit(1)
-    if c % 20 == 0:
+    del x, ref, k
+    if c % int(os.environ.get("SOAK_EVERY", 20)) == 0:
         print(f"case {c} ok ({typ} n={n} kind={kind} mode={mode}) t={time.time()-t_start:.0f}s", flush=True)
 print(f"all {cases} cases ok in {time.time()-t_start:.0f}s")
