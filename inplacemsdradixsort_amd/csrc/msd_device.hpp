@@ -649,7 +649,7 @@ template <typename K, typename V> struct DirectLds {
 __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int need, uint64_t &mask_out)
 {
 	uint64_t cand = __ballot(elig), selm = 0;
-	if (__popcll(cand) > need) {
+	if ((int)__popcll(cand) > need) {
 #pragma unroll
 		for (int bit = 9; bit >= 0; --bit) {
 			const uint64_t zeros = cand & ~__ballot((v >> bit) & 1u);
