@@ -98,7 +98,7 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t nslow;         // counting-sort segments the fast kernel left to count_walk_kernel
 	uint32_t count_ticket2; // work ticket of count_walk_kernel
 	uint32_t nevict;        // per round: side-store blocks handed out for evictions
-	uint32_t pad[2];
+	uint32_t leaf_ticket[2]; // work tickets of the two leaf_count_sort launches
 };
 
 // ---------------------------------------------------------------- utilities
@@ -1993,8 +1993,11 @@ template <typename K, typename V> struct LeafCountLds {
 template <typename K, typename V>
 __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K *__restrict__ keys,
 	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs,
-	Segment *__restrict__ fallback, Counters *__restrict__ ctr)
+	Segment *__restrict__ fallback, Counters *__restrict__ ctr, uint32_t *__restrict__ ticket)
 {
+	// Persistent workgroups (one per CU fits the LDS): segments by ticket; the next segment's elements are
+	// loaded (branch-free) as soon as the current ones have left the registers for LDS, so its load
+	// latency is hidden behind the fix-up and the write-back of the current one.
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
 	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, CAP = TH * KPT;
@@ -2002,140 +2005,166 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 	K *xk = reinterpret_cast<K *>(smem);
 	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * (sizeof(K) + (HV ? 8 : 0))); // 2 x 16-bit counters per word
-	uint32_t *wtot = cw + ((size_t)1 << kLeafCountBits) / 2; // 16 wave totals, [16] flag
+	uint32_t *wtot = cw + ((size_t)1 << kLeafCountBits) / 2; // 16 wave totals, [16] flag, [17] next ticket
 	K *s_or = reinterpret_cast<K *>(wtot + 32);              // [2] OR / AND of the keys
 	if (blockIdx.x >= nsegs) return;
-	const Segment sg = segs[blockIdx.x];
-	const uint32_t n = (uint32_t)sg.count, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+	Segment sg = segs[blockIdx.x];
 	K kr[KPT];
 	uint64_t vr[HV ? KPT : 1];
-	K k_or = 0, k_and = ~(K)0;
+	auto prefetch = [&](const Segment &g) {
+		const uint32_t cnt = (uint32_t)g.count;
 #pragma unroll
-	for (int i = 0; i < KPT; ++i) {
-		const uint32_t idx = i * TH + tid;
-		kr[i] = 0;
-		if constexpr (HV) vr[i] = 0;
-		if (idx < n) {
-			kr[i] = keys[sg.start + idx];
-			if constexpr (HV) vr[i] = vals[sg.start + idx];
-			k_or |= kr[i];
-			k_and &= kr[i];
+		for (int i = 0; i < KPT; ++i) { // past-the-end lanes re-read the last element (ignored later)
+			if ((uint32_t)(i * TH) < cnt) { // (uniform: rows beyond the segment are not loaded at all)
+				const uint32_t idx = min((uint32_t)(i * TH) + tid, cnt - 1u);
+				kr[i] = keys[g.start + idx];
+				if constexpr (HV) vr[i] = vals[g.start + idx];
+			}
 		}
-	}
-	if (tid == 0) {
-		s_or[0] = 0;
-		s_or[1] = ~(K)0;
-		wtot[16] = 0;
-	}
-	// (measured: fewer counters for small segments make the kernel slower -- more equal-prefix groups to fix up)
-	const uint32_t cbits = (uint32_t)kLeafCountBits;
-	const uint32_t nwords = (1u << cbits) / 2; // 2 x 16-bit counters per word
-	for (uint32_t j = tid; j < nwords; j += TH) cw[j] = 0;
-	__syncthreads();
+	};
+	prefetch(sg);
+	for (;;) {
+		const uint32_t n = (uint32_t)sg.count;
+		K k_or = 0, k_and = ~(K)0;
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		k_or |= __shfl_xor(k_or, o);
-		k_and &= __shfl_xor(k_and, o);
-	}
-	if (lane == 0) {
-		if constexpr (sizeof(K) == 4) {
-			atomicOr(reinterpret_cast<unsigned int *>(&s_or[0]), (unsigned int)k_or);
-			atomicAnd(reinterpret_cast<unsigned int *>(&s_or[1]), (unsigned int)k_and);
-		} else {
-			atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
-			atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
+		for (int i = 0; i < KPT; ++i) {
+			if ((uint32_t)(i * TH) + tid < n) {
+				k_or |= kr[i];
+				k_and &= kr[i];
+			}
 		}
-	}
-	__syncthreads();
-	const K openmask = sg.bits >= sizeof(K) * 8 ? ~(K)0 : (((K)1 << sg.bits) - 1);
-	const K vopen = (s_or[0] ^ s_or[1]) & openmask;
-	if (vopen == 0) return; // constant on the open bits: already sorted
-	const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
-	const uint32_t shift = nbits > cbits ? nbits - cbits : 0;
-	const uint32_t mask = (1u << (nbits - shift)) - 1u;
-	uint32_t rk[KPT];
+		if (tid == 0) {
+			s_or[0] = 0;
+			s_or[1] = ~(K)0;
+			wtot[16] = 0;
+			wtot[17] = atomicAdd(ticket, 1u) + gridDim.x;
+		}
+		for (uint32_t j = tid; j < ((uint32_t)1 << kLeafCountBits) / 2; j += TH) cw[j] = 0;
+		__syncthreads();
 #pragma unroll
-	for (int i = 0; i < KPT; ++i) {
-		rk[i] = 0;
-		if ((uint32_t)(i * TH) + tid < n) {
-			const uint32_t v = (uint32_t)(kr[i] >> shift) & mask, sh = 16u * (v & 1u);
-			rk[i] = (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu;
+		for (int o = 32; o > 0; o >>= 1) {
+			k_or |= __shfl_xor(k_or, o);
+			k_and &= __shfl_xor(k_and, o);
 		}
-	}
-	__syncthreads();
-	// counts -> exclusive positions, in place; thread t owns wpt consecutive words
-	const uint32_t wpt = nwords >= (uint32_t)TH ? nwords / TH : 1u;
-	const uint32_t w0 = tid * wpt;
-	uint32_t tot = 0;
-	if (w0 < nwords) {
-		for (uint32_t j = 0; j < wpt; ++j) {
-			const uint32_t x = cw[w0 + j];
-			tot += (x & 0xFFFFu) + (x >> 16);
+		if (lane == 0) {
+			if constexpr (sizeof(K) == 4) {
+				atomicOr(reinterpret_cast<unsigned int *>(&s_or[0]), (unsigned int)k_or);
+				atomicAnd(reinterpret_cast<unsigned int *>(&s_or[1]), (unsigned int)k_and);
+			} else {
+				atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
+				atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
+			}
 		}
-	}
-	const uint32_t inc = wave_incl_scan(tot);
-	if (lane == 63) wtot[w] = inc;
-	__syncthreads();
-	uint32_t run = inc - tot;
-	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
-	if (w0 < nwords) {
-		for (uint32_t j = 0; j < wpt; ++j) {
-			const uint32_t x = cw[w0 + j];
-			const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
-			cw[w0 + j] = run | ((run + lo) << 16);
-			run += lo + hi;
-		}
-	}
-	__syncthreads();
+		__syncthreads();
+		const uint32_t nxt = wtot[17];
+		const K openmask = sg.bits >= sizeof(K) * 8 ? ~(K)0 : (((K)1 << sg.bits) - 1);
+		const K vopen = (s_or[0] ^ s_or[1]) & openmask;
+		Segment nsg = sg;
+		bool fetched = false;
+		if (vopen != 0) { // (uniform) otherwise constant on the open bits: already sorted
+			const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
+			const uint32_t shift = nbits > (uint32_t)kLeafCountBits ? nbits - kLeafCountBits : 0;
+			const uint32_t mask = (1u << (nbits - shift)) - 1u;
+			uint32_t rk[KPT];
 #pragma unroll
-	for (int i = 0; i < KPT; ++i) {
-		if ((uint32_t)(i * TH) + tid < n) {
-			const uint32_t v = (uint32_t)(kr[i] >> shift) & mask;
-			const uint32_t p = ((cw[v >> 1] >> (16u * (v & 1u))) & 0xFFFFu) + rk[i];
-			xk[p] = kr[i];
-			if constexpr (HV) xv[p] = vr[i];
-		}
-	}
-	__syncthreads();
-	if (shift) { // more bits vary than were counted: order the groups of equal counted bits by whole keys
-		const K lowmask = ((K)1 << shift) - 1;
-		bool too_long = false;
-		if ((vopen & lowmask) != 0) {
-			for (uint32_t i = tid; i < n; i += TH) {
-				const K hi = xk[i] >> shift;
-				if ((i == 0 || (xk[i - 1] >> shift) != hi) && i + 1 < n && (xk[i + 1] >> shift) == hi) {
-					uint32_t e = i + 2;
-					while (e < n && (xk[e] >> shift) == hi) ++e;
-					if (e - i > 48) {
-						too_long = true;
-					} else {
-						for (uint32_t a = i + 1; a < e; ++a) {
-							const K ka = xk[a];
-							uint64_t va = 0;
-							if constexpr (HV) va = xv[a];
-							uint32_t b = a;
-							while (b > i && xk[b - 1] > ka) {
-								xk[b] = xk[b - 1];
-								if constexpr (HV) xv[b] = xv[b - 1];
-								--b;
+			for (int i = 0; i < KPT; ++i) {
+				rk[i] = 0;
+				if ((uint32_t)(i * TH) + tid < n) {
+					const uint32_t v = (uint32_t)(kr[i] >> shift) & mask, sh = 16u * (v & 1u);
+					rk[i] = (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu;
+				}
+			}
+			__syncthreads();
+			// counts -> exclusive positions, in place; thread t owns 8 words
+			constexpr uint32_t WPT = (((uint32_t)1 << kLeafCountBits) / 2) / TH;
+			static_assert(WPT >= 1, "counter words per thread");
+			const uint32_t w0 = tid * WPT;
+			uint32_t tot = 0;
+#pragma unroll
+			for (uint32_t j = 0; j < WPT; ++j) {
+				const uint32_t x = cw[w0 + j];
+				tot += (x & 0xFFFFu) + (x >> 16);
+			}
+			const uint32_t inc = wave_incl_scan(tot);
+			if (lane == 63) wtot[w] = inc;
+			__syncthreads();
+			uint32_t run = inc - tot;
+			for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
+#pragma unroll
+			for (uint32_t j = 0; j < WPT; ++j) {
+				const uint32_t x = cw[w0 + j];
+				const uint32_t lo = x & 0xFFFFu, hi = x >> 16;
+				cw[w0 + j] = run | ((run + lo) << 16);
+				run += lo + hi;
+			}
+			__syncthreads();
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) {
+				if ((uint32_t)(i * TH) + tid < n) {
+					const uint32_t v = (uint32_t)(kr[i] >> shift) & mask;
+					const uint32_t p = ((cw[v >> 1] >> (16u * (v & 1u))) & 0xFFFFu) + rk[i];
+					xk[p] = kr[i];
+					if constexpr (HV) xv[p] = vr[i];
+				}
+			}
+			// the registers are free: the next segment's elements start travelling
+			if (nxt < nsegs) {
+				nsg = segs[nxt];
+				prefetch(nsg);
+				fetched = true;
+			}
+			__syncthreads();
+			bool bad = false;
+			if (shift) { // more bits vary than were counted: order the groups of equal counted bits by whole keys
+				const K lowmask = ((K)1 << shift) - 1;
+				bool too_long = false;
+				if ((vopen & lowmask) != 0) {
+					for (uint32_t i = tid; i < n; i += TH) {
+						const K hi = xk[i] >> shift;
+						if ((i == 0 || (xk[i - 1] >> shift) != hi) && i + 1 < n && (xk[i + 1] >> shift) == hi) {
+							uint32_t e = i + 2;
+							while (e < n && (xk[e] >> shift) == hi) ++e;
+							if (e - i > 48) {
+								too_long = true;
+							} else {
+								for (uint32_t a = i + 1; a < e; ++a) {
+									const K ka = xk[a];
+									uint64_t va = 0;
+									if constexpr (HV) va = xv[a];
+									uint32_t b = a;
+									while (b > i && xk[b - 1] > ka) {
+										xk[b] = xk[b - 1];
+										if constexpr (HV) xv[b] = xv[b - 1];
+										--b;
+									}
+									xk[b] = ka;
+									if constexpr (HV) xv[b] = va;
+								}
 							}
-							xk[b] = ka;
-							if constexpr (HV) xv[b] = va;
 						}
 					}
 				}
+				if (too_long) wtot[16] = 1;
+				__syncthreads();
+				bad = wtot[16] != 0;
+				// nothing has been written back yet: the general LDS sort takes the segment as it is
+				if (bad && tid == 0) fallback[atomicAdd(&ctr->nfallback, 1u)] = sg;
+			}
+			if (!bad) {
+				for (uint32_t idx = tid; idx < n; idx += TH) {
+					keys[sg.start + idx] = xk[idx];
+					if constexpr (HV) vals[sg.start + idx] = xv[idx];
+				}
 			}
 		}
-		if (too_long) wtot[16] = 1;
-		__syncthreads();
-		if (wtot[16]) { // nothing has been written back yet: the general LDS sort takes the segment as it is
-			if (tid == 0) fallback[atomicAdd(&ctr->nfallback, 1u)] = sg;
-			return;
+		if (nxt >= nsegs) break;
+		if (!fetched) {
+			nsg = segs[nxt];
+			prefetch(nsg);
 		}
-	}
-	for (uint32_t idx = tid; idx < n; idx += TH) {
-		keys[sg.start + idx] = xk[idx];
-		if constexpr (HV) vals[sg.start + idx] = xv[idx];
+		sg = nsg;
+		__syncthreads(); // LDS (exchange buffers, counters, flags) is reused
 	}
 }
 

@@ -771,14 +771,15 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		const uint32_t nsm = nsmall_host + (HV ? ncount_host : 0u); // tuples: both lists hold leaf_count work
 		if (nsmall_host) {
 			constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
-			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(nsmall_host), dim3(C::SORT_TH), leaf_lds, c->stream,
-					   keys, vals, small, nsmall_host, small + nsmall_host, ctr);
+			// persistent workgroups (one per CU fits the LDS) with prefetch of the next segment
+			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(nsmall_host, (uint32_t)c->sm_count)), dim3(C::SORT_TH), leaf_lds, c->stream,
+					   keys, vals, small, nsmall_host, small + nsmall_host, ctr, &ctr->leaf_ticket[0]);
 			HIPCHK(c, hipGetLastError());
 		}
 		if (HV && ncount_host) {
 			constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
-			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(ncount_host), dim3(C::SORT_TH), leaf_lds, c->stream,
-					   keys, vals, small_count, ncount_host, small + nsmall_host, ctr);
+			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count)), dim3(C::SORT_TH), leaf_lds, c->stream,
+					   keys, vals, small_count, ncount_host, small + nsmall_host, ctr, &ctr->leaf_ticket[1]);
 			HIPCHK(c, hipGetLastError());
 		}
 		(void)nsm;
