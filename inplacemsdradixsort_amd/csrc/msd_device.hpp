@@ -48,7 +48,9 @@ template <> struct Cfg<uint32_t, NoVal> {
 };
 template <> struct Cfg<uint64_t, NoVal> {
 	static constexpr int B = 32, T = 4096, TH = 1024;
-	static constexpr int SORT_TH = 1024, SORT_KPT = 12; // 12288
+	// 17408 u64 keys (139 KiB of the 160 KiB LDS): the 2^14-key children of two 8-bit rounds over 2^30 keys
+	// are leaves, no third round
+	static constexpr int SORT_TH = 1024, SORT_KPT = 17;
 };
 template <> struct Cfg<uint64_t, uint64_t> {
 	static constexpr int B = 32, T = 2048, TH = 1024;
@@ -1984,10 +1986,14 @@ __global__ __launch_bounds__(kCountTh, 8) void count_walk_kernel(K *__restrict__
 // whole-key insertion (their first element does it); a group longer than 48 sends the untouched
 // segment to the general LDS sort.  Output is stored coalesced.
 constexpr int kLeafCountBits = 14;
+// counted bits of the leaf per type: u64 keys trade one bit for a larger exchange buffer (see Cfg)
+template <typename K, typename V> struct LeafBits {
+	static constexpr int value = (sizeof(K) == 8 && !has_val<V>::value) ? 13 : kLeafCountBits;
+};
 template <typename K, typename V> struct LeafCountLds {
 	static constexpr int CAP = Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT;
 	static constexpr size_t bytes = (size_t)CAP * (sizeof(K) + (has_val<V>::value ? 8 : 0)) +
-					((size_t)1 << kLeafCountBits) * 2 + 192;
+					((size_t)1 << LeafBits<K, V>::value) * 2 + 192;
 };
 
 template <typename K, typename V>
@@ -2000,12 +2006,12 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 	// latency is hidden behind the fix-up and the write-back of the current one.
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
-	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, CAP = TH * KPT;
+	constexpr int TH = C::SORT_TH, KPT = C::SORT_KPT, CAP = TH * KPT, LB = LeafBits<K, V>::value;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	K *xk = reinterpret_cast<K *>(smem);
 	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * (sizeof(K) + (HV ? 8 : 0))); // 2 x 16-bit counters per word
-	uint32_t *wtot = cw + ((size_t)1 << kLeafCountBits) / 2; // 16 wave totals, [16] flag, [17] next ticket
+	uint32_t *wtot = cw + ((size_t)1 << LB) / 2; // 16 wave totals, [16] flag, [17] next ticket
 	K *s_or = reinterpret_cast<K *>(wtot + 32);              // [2] OR / AND of the keys
 	if (blockIdx.x >= nsegs) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -2040,7 +2046,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 			wtot[16] = 0;
 			wtot[17] = atomicAdd(ticket, 1u) + gridDim.x;
 		}
-		for (uint32_t j = tid; j < ((uint32_t)1 << kLeafCountBits) / 2; j += TH) cw[j] = 0;
+		for (uint32_t j = tid; j < ((uint32_t)1 << LB) / 2; j += TH) cw[j] = 0;
 		__syncthreads();
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
@@ -2064,7 +2070,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 		bool fetched = false;
 		if (vopen != 0) { // (uniform) otherwise constant on the open bits: already sorted
 			const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
-			const uint32_t shift = nbits > (uint32_t)kLeafCountBits ? nbits - kLeafCountBits : 0;
+			const uint32_t shift = nbits > (uint32_t)LB ? nbits - LB : 0;
 			const uint32_t mask = (1u << (nbits - shift)) - 1u;
 			uint32_t rk[KPT];
 #pragma unroll
@@ -2077,7 +2083,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 			}
 			__syncthreads();
 			// counts -> exclusive positions, in place; thread t owns 8 words
-			constexpr uint32_t WPT = (((uint32_t)1 << kLeafCountBits) / 2) / TH;
+			constexpr uint32_t WPT = (((uint32_t)1 << LB) / 2) / TH;
 			static_assert(WPT >= 1, "counter words per thread");
 			const uint32_t w0 = tid * WPT;
 			uint32_t tot = 0;

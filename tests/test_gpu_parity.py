@@ -142,7 +142,7 @@ def test_golden_pairs(ctx):
     assert (g["keys_in"][ro] == ko).all() and (np.sort(ro) == g["rids_in"]).all()
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 33, 1000, 12288, 12289, 100003, 1 << 20, (1 << 22) + 5])
+@pytest.mark.parametrize("n", [0, 1, 2, 33, 1000, 12288, 12289, 17408, 17409, 100003, 1 << 20, (1 << 22) + 5])
 @pytest.mark.parametrize("kind", ["full", "hi32zero", "dup", "const"])
 def test_sort_u64_equals_oracle(ctx, n, kind):
     if kind == "full":
