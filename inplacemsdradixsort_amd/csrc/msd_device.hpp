@@ -17,8 +17,16 @@
 //                        the hole and inherits the vacated slot.
 //   C  cleanup_kernel    bucket heads/tails are filled from the stripes'
 //                        partial buffers.
-// Segments that fit LDS are finished by lds_sort_kernel (stable LSD passes inside
-// LDS; ranks from wavefront ballot/popcount match-any).
+//   A' classify_direct_kernel (rounds whose buckets are about equally big and free of
+//                        runs): bucket boundaries are known before the pass (sampled /
+//                        exactly counted), every workgroup reads its own share of each
+//                        bucket's region and writes completed blocks straight into it,
+//                        so that B only moves the few misplaced blocks.
+// Leaves: count_place_kernel / count_walk_kernel (keys only, <= 16 open bits: one counting
+// pass over all of them), bigcount_* (the same for segments of any size),
+// leaf_count_sort_kernel (everything else that fits LDS: one counting pass over the top
+// varying bits + group fix-up), lds_sort_kernel (general fallback: stable LSD passes
+// inside LDS; ranks from wavefront ballot/popcount match-any).
 //
 // Everything here is integer/byte work bound by HBM; there is no MFMA use.
 #pragma once

@@ -15,7 +15,7 @@
 
 using namespace msd;
 
-#define MSD_VERSION "inplacemsdradixsort_amd 0.1 (gfx950)"
+#define MSD_VERSION "inplacemsdradixsort_amd 0.2 (gfx950)"
 
 struct PhaseRec {
 	const char *name;
