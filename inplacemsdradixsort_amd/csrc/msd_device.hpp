@@ -2244,14 +2244,14 @@ __global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict
 						const int l = __ffsll((long long)todo) - 1;
 						const uint32_t vl = (uint32_t)__shfl((int)v, l);
 						const uint64_t same = __ballot(mine && v == vl);
-						if (__popcll(same) < 8) break;
+						if (__popcll(same) < 4) break;
 						if ((int)(tid & 63) == l) atomicAdd(&cw[vl], (uint32_t)__popcll(same));
 						if (v == vl) mine = false;
 						hot = true;
 					}
 				} else if (u == 0) { // probe: does the first lane's value repeat in this wave?
 					const uint32_t vl = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-					hot = __popcll(__ballot(mine && v == vl)) >= 8;
+					hot = __popcll(__ballot(mine && v == vl)) >= 4;
 				}
 				if (mine) atomicAdd(&cw[v], 1u);
 			}
