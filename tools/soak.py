@@ -72,6 +72,26 @@ for c in range(cases):
     else:
         ref = torch.sort(x).values
         k = x.to(torch.int32) if False else (x - ((x >> 31) << 32)).to(torch.int32)
+    if c % 7 == 3 and not off and eb == bits:  # the one-digit partition (the pass before the multi-GPU exchange)
+        rb = int(torch.randint(1, 9, (1,)).item())
+        sh = int(torch.randint(0, bits - rb + 1, (1,)).item())
+        r = torch.arange(n, device="cuda", dtype=torch.int64) if typ == "pairs" else None
+        cnt = ctx.partition(k, sh, rb, r)
+        ku = (k.to(torch.int64) & 0xFFFFFFFF) if bits == 32 else k
+        xu = x
+        d = (ku >> sh) & ((1 << rb) - 1)
+        ok = bool((d[1:] >= d[:-1]).all()) if n > 1 else True
+        d0 = (xu >> sh) & ((1 << rb) - 1)
+        ok = ok and bool((torch.bincount(d0, minlength=1 << rb) == cnt).all())
+        srt = (lambda t: torch.sort(t ^ (-(1 << 63))).values) if bits == 64 else (lambda t: torch.sort(t).values)
+        ok = ok and bool((srt(ku) == srt(xu)).all())
+        if r is not None:
+            ok = ok and bool(((r >= 0) & (r < n)).all()) and bool((x[r] == k).all())
+        if not ok:
+            print(f"FAIL partition case {c}: typ={typ} n={n} kind={kind} mode={mode} shift={sh} radix_bits={rb}", ctx.stats(), flush=True)
+            sys.exit(1)
+        del x, ref, k
+        continue
     if off:  # the head must stay untouched, the tail sorted
         if bits == 64:
             ref = torch.cat([x[:off], torch.sort(x[off:] ^ (-(1 << 63))).values ^ (-(1 << 63))])
