@@ -2265,6 +2265,24 @@ __global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict
 	}
 }
 
+// One launch clears what a round starts from (a handful of separate memsets cost a few microseconds of
+// idle GPU each): the per-round counters, the per-parent plans of a direct round, the scan's tile state.
+__global__ __launch_bounds__(256) void round_init_kernel(Counters *__restrict__ ctr, uint32_t *__restrict__ plan_words,
+	uint64_t nplan_words, unsigned long long *__restrict__ scan_state, uint64_t ntiles, uint32_t *__restrict__ scan_ctr)
+{
+	const uint64_t i0 = (uint64_t)blockIdx.x * 256 + threadIdx.x, step = (uint64_t)gridDim.x * 256;
+	if (i0 == 0) {
+		ctr->nholes = 0;
+		ctr->hole_cursor = 0;
+		ctr->next_parents = 0;
+		ctr->nevict = 0;
+		ctr->direct_uneven = 0;
+		scan_ctr[0] = scan_ctr[1] = scan_ctr[2] = scan_ctr[3] = 0;
+	}
+	for (uint64_t i = i0; i < nplan_words; i += step) plan_words[i] = 0;
+	for (uint64_t i = i0; i < ntiles; i += step) scan_state[i] = 0;
+}
+
 // counts -> exclusive prefix (in place); also records the segment's common key prefix.
 // Wave w owns the contiguous values [w*nv/16, (w+1)*nv/16) and walks them 64 at a time (coalesced).
 template <typename K>

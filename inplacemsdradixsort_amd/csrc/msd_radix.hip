@@ -356,12 +356,14 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 
 // scan helper on the context stream
 static int run_scan(msd_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n,
-		    unsigned long long *state, uint32_t *ctr, uint32_t *err)
+		    unsigned long long *state, uint32_t *ctr, uint32_t *err, bool cleared = false)
 {
 	if (n == 0) return MSD_OK;
 	const size_t ntiles = (n + kScanTile - 1) / kScanTile;
-	HIPCHK(c, hipMemsetAsync(state, 0, ntiles * sizeof(unsigned long long), c->stream));
-	HIPCHK(c, hipMemsetAsync(ctr, 0, 16, c->stream));
+	if (!cleared) { // (the sort's rounds clear the state in round_init_kernel)
+		HIPCHK(c, hipMemsetAsync(state, 0, ntiles * sizeof(unsigned long long), c->stream));
+		HIPCHK(c, hipMemsetAsync(ctr, 0, 16, c->stream));
+	}
 	hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)ntiles), dim3(kScanTh), 0, c->stream, in, out, n, state, ctr, err);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
@@ -539,9 +541,12 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			small_count = c->lists + 3 * c->lists_cap;
 		}
 		const uint32_t small_cap = (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu);
-		if (round > 0) {
-			HIPCHK(c, hipMemsetAsync(ctr, 0, 3 * sizeof(uint32_t), c->stream)); // nholes, hole_cursor, next_parents
-			HIPCHK(c, hipMemsetAsync(&ctr->nevict, 0, sizeof(uint32_t), c->stream));
+		{ // per-round counters, per-parent plans, scan state: one launch
+			const uint64_t plan_words = (np <= kDirectMaxParents ? np : 1) * sizeof(DirectPlan) / sizeof(uint32_t);
+			const uint64_t ntiles = (nc + kScanTile - 1) / kScanTile + 1;
+			const unsigned grid = (unsigned)std::min<uint64_t>(1024, (std::max(plan_words, ntiles) + 255) / 256 + 1);
+			hipLaunchKernelGGL(round_init_kernel, dim3(grid), dim3(256), 0, c->stream, ctr, reinterpret_cast<uint32_t *>(rb.plans),
+					   plan_words, rb.scan_state, ntiles, rb.scan_ctr);
 		}
 		// ---- upload tables
 		{
@@ -577,8 +582,6 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		for (size_t i = 0; i < np && try_direct; ++i)
 			max_piece = std::max<uint64_t>(max_piece, rp.parents[i].count / B / (rp.parents[i].stripe_hi - rp.parents[i].stripe_lo) + 2);
 		if (try_direct && max_piece < 65535) {
-			HIPCHK(c, hipMemsetAsync(rb.plans, 0, np * sizeof(DirectPlan), c->stream));
-			HIPCHK(c, hipMemsetAsync(&ctr->direct_uneven, 0, sizeof(uint32_t), c->stream));
 			if (np == 1) {
 				// sample about 2^22 keys or more, as runs of 256 spread evenly over the parent
 				const uint64_t nruns = rp.parents[0].count / 256;
@@ -620,7 +623,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr,
 				   (uint32_t)std::min<uint64_t>(rp.nslots, 0xFFFFFFFFu), (uint32_t)(2 * nc + kMinChains));
 		{
-			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors);
+			int rc = run_scan(c, rb.ca.list_len, rb.ca.list_base, nc, rb.scan_state, rb.scan_ctr, &ctr->errors, true);
 			if (rc) return rc;
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
