@@ -13,6 +13,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
+# diagnostic build with in-kernel cycle stamps (tools/stamps_run.py); never what tests or bench.py load
+STAMPS_LIB = os.path.join(HERE, "libinpmsdradix_hip_stamps.so")
 SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
 DEPS = SOURCES + ["msd_device.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
                   os.path.join("..", "..", "include", "msb_64.h")]
@@ -44,6 +46,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     subprocess.check_call(cmd)
     os.replace(LIB + ".tmp", LIB)
     return LIB
+
+
+def build_stamps() -> str:
+    cmd = [_hipcc(), *FLAGS, "-DMSD_STAMPS", *[os.path.join(CSRC, s) for s in SOURCES], "-o", STAMPS_LIB]
+    subprocess.check_call(cmd)
+    return STAMPS_LIB
 
 
 if __name__ == "__main__":

@@ -111,6 +111,44 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t leaf_ticket[2]; // work tickets of the two leaf_count_sort launches
 };
 
+// ---------------------------------------------------------------- diagnostics
+// -DMSD_STAMPS (tools/stamps_build.sh, never the shipped library): wave 0 (a "bucket wave") and the last wave of
+// every classify_direct workgroup add the shader cycles they spend in each section of the tile loop to
+// g_stamps[which wave][section]; read back with msd_debug_stamps().
+#ifdef MSD_STAMPS
+__device__ unsigned long long g_stamps[2][16];
+#define MSD_STAMP_DECL unsigned long long st_acc[12] = {}, st_last = 0
+#define MSD_STAMP_START()                                                                      \
+	do {                                                                                    \
+		__builtin_amdgcn_sched_barrier(0);                                              \
+		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); \
+		__builtin_amdgcn_sched_barrier(0);                                              \
+	} while (0)
+#define MSD_STAMP(i)                                                                            \
+	do {                                                                                    \
+		unsigned long long now_;                                                        \
+		__builtin_amdgcn_sched_barrier(0);                                              \
+		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");    \
+		__builtin_amdgcn_sched_barrier(0);                                              \
+		st_acc[i] += now_ - st_last;                                                    \
+		st_last = now_;                                                                 \
+	} while (0)
+#define MSD_STAMP_TICK(i) st_acc[i] += 1
+#define MSD_STAMP_FLUSH(nwaves)                                                                 \
+	do {                                                                                    \
+		const unsigned wv_ = threadIdx.x >> 6;                                          \
+		if ((threadIdx.x & 63) == 0 && (wv_ == 0 || wv_ == (nwaves) - 1)) {            \
+			for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[wv_ ? 1 : 0][i_], st_acc[i_]); \
+		}                                                                               \
+	} while (0)
+#else
+#define MSD_STAMP_DECL
+#define MSD_STAMP_START() do {} while (0)
+#define MSD_STAMP(i) do {} while (0)
+#define MSD_STAMP_TICK(i) do {} while (0)
+#define MSD_STAMP_FLUSH(nwaves) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------- utilities
 
 template <typename K> __device__ __forceinline__ uint32_t digit_of(K key, uint32_t shift, uint32_t mask)
@@ -852,7 +890,11 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	bool okB = load_tile(kregB, vregB);
 	uint32_t par = 0;
 
+	MSD_STAMP_DECL;
+	MSD_STAMP_START();
 	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1], bool &okc, uint32_t &nc) {
+		MSD_STAMP(9); // flush of the previous tile + loop overhead
+		MSD_STAMP_TICK(11);
 		// ---- ranks
 		uint32_t dr[KPT];
 #pragma unroll
@@ -863,7 +905,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 				dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
 			}
 		}
+		MSD_STAMP(0); // ranks (incl. the wait for this tile's keys)
 		__syncthreads(); // B1
+		MSD_STAMP(1); // barrier B1
 		// ---- per bucket: completed blocks take a consumed slot of the bucket's own piece if there is one
 		uint32_t pend_blocks = 0, own_r = 0, sel_state = 0;
 		if (tid < kP) {
@@ -899,7 +943,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 			tmp[6 + (par ^ 1)] = 0;
 			tmp[12 + (par ^ 1)] = 0;
 		}
+		MSD_STAMP(2); // per-bucket bookkeeping
 		__syncthreads(); // B2a
+		MSD_STAMP(3); // barrier B2a
 		if (tmp[6 + par]) { // (uniform) some bucket has no consumed slot left in its own piece: take one of another piece
 			for (uint32_t q = 0; q < pend_blocks; ++q) {
 				uint32_t slot = NONE, e = (tid * 37u + 1u) & (kP - 1);
@@ -937,9 +983,11 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 			}
 			__syncthreads(); // B2b
 		}
+		MSD_STAMP(4); // steals + B2b
 		// the next reads are chosen after the barrier: the other twelve waves scatter meanwhile
 		// (the choice is needed only when the next tile's loads are issued, after B3)
 		if (tid < kP) select_reads(cw[tid] >> 16, sel_state & 0xFFFFu, (sel_state >> 16) & 3u, sel_state >> 18, &tmp[12 + par]);
+		MSD_STAMP(5); // read selection
 		const uint32_t nx = min(tmp[2 + par], (uint32_t)L::XT);
 		const uint32_t njobs = tmp[par];
 		// ---- scatter
@@ -983,8 +1031,11 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 				}
 			}
 		}
+		MSD_STAMP(6); // scatter
 		__syncthreads(); // B3
+		MSD_STAMP(7); // barrier B3
 		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (measured: leaving it to the compiler costs 0.1 ms per launch)
+		MSD_STAMP(8); // vmcnt(0): the previous flush's stores (and the loads issued a tile ago)
 		nc = tmp[12 + par];
 		okc = load_tile(kc, vc);
 		// ---- flush completed buffers to their slots
@@ -1007,6 +1058,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 		tile(kregB, vregB, okB, nB);
 	}
 	__syncthreads();
+	MSD_STAMP(9);
 #pragma unroll
 	for (int i = 0; i < KPT; ++i) {
 		if (dat[i] != NONE) {
@@ -1053,6 +1105,8 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 		lo_keys[at] = headk[tid];
 		if constexpr (HV) lo_vals[at] = headv[tid];
 	}
+	MSD_STAMP(10); // epilogue
+	MSD_STAMP_FLUSH(TH / 64);
 }
 
 // ------------------------------------------------- child geometry per parent

@@ -1118,6 +1118,19 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	return MSD_OK;
 }
 
+#ifdef MSD_STAMPS
+// diagnostic build only: per-section shader cycles of classify_direct_kernel, [wave 0 | last wave][section]; resets them
+int msd_debug_stamps(uint64_t *out)
+{
+	unsigned long long h[2][16];
+	if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return MSD_EHIP;
+	memcpy(out, h, sizeof h);
+	memset(h, 0, sizeof h);
+	if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h) != hipSuccess) return MSD_EHIP;
+	return MSD_OK;
+}
+#endif
+
 int msd_set_profiling(msd_ctx *c, int on)
 {
 	if (!c) return MSD_EINVAL;
