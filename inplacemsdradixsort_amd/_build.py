@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
 # diagnostic build with in-kernel cycle stamps (tools/stamps_run.py); never what tests or bench.py load
 STAMPS_LIB = os.path.join(HERE, "libinpmsdradix_hip_stamps.so")
 SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
-DEPS = SOURCES + ["msd_device.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
+DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
                   os.path.join("..", "..", "include", "msb_64.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wno-unused-result"]
@@ -48,10 +48,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_stamps() -> str:
-    cmd = [_hipcc(), *FLAGS, "-DMSD_STAMPS", *[os.path.join(CSRC, s) for s in SOURCES], "-o", STAMPS_LIB]
+def build_stamps(extra=(), out: str = STAMPS_LIB) -> str:
+    cmd = [_hipcc(), *FLAGS, "-DMSD_STAMPS", *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     subprocess.check_call(cmd)
-    return STAMPS_LIB
+    return out
+
+
+def build_variant(name: str, extra=()) -> str:
+    """An experimental build with extra -D flags next to the product library (tools/variant_run.py)."""
+    out = os.path.join(HERE, f"libinpmsdradix_hip_{name}.so")
+    subprocess.check_call([_hipcc(), *FLAGS, *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", out])
+    return out
 
 
 if __name__ == "__main__":

@@ -114,6 +114,31 @@ class MsdContext:
             self._ok(self._L.msd_partition_u64(self._h, self._ptr(keys, 8), keys.numel(), shift, radix_bits, C.c_void_p(cnt.data_ptr())))
         return cnt
 
+    # ---- splitter service (reference: src/msb_64.c:1511-1521, :1304-1322, :188-204)
+    def sample_u32(self, keys, m: int, seed: int = 0x5EED0007):
+        """m keys drawn from the (unsorted) tensor at pseudo-random positions mulhi(splitmix64(seed + i), n)."""
+        torch = _torch()
+        out = torch.empty(m, dtype=torch.int32, device=keys.device)
+        self._ok(self._L.msd_sample_u32(self._h, self._ptr(keys, 4), keys.numel(), m, seed, C.c_void_p(out.data_ptr())))
+        return out
+
+    def splitters_u32(self, sorted_sample, parts: int):
+        """parts-1 equi-depth delimiters (u32 bit patterns in an int32 tensor) with the reference's duplicate rule."""
+        torch = _torch()
+        out = torch.empty(max(parts - 1, 0), dtype=torch.int32, device=sorted_sample.device)
+        self._ok(self._L.msd_splitters_u32(self._h, self._ptr(sorted_sample, 4), sorted_sample.numel(), parts,
+                                           C.c_void_p(out.data_ptr())))
+        return out
+
+    def partition_by_splitters(self, keys, delims, parts: int):
+        """One in-place pass: range p = keys in (delims[p-1], delims[p]]; returns the range sizes (int64 tensor)."""
+        torch = _torch()
+        cnt = torch.zeros(parts, dtype=torch.int64, device=keys.device)
+        dp = self._ptr(delims, 4) if parts > 1 else C.c_void_p(0)
+        self._ok(self._L.msd_partition_by_splitters_u32(self._h, self._ptr(keys, 4), keys.numel(), dp, parts,
+                                                        C.c_void_p(cnt.data_ptr())))
+        return cnt
+
     def check(self, keys, rids=None) -> Tuple[int, int, int]:
         """(violations, sum, xor): device form of the reference's check()."""
         v, s, x = C.c_uint64(), C.c_uint64(), C.c_uint64()

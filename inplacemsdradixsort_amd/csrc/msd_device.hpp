@@ -71,7 +71,7 @@ struct Parent {
 	uint32_t width;      // 1..8
 	uint32_t child_base; // global child index of digit 0
 	uint32_t stripe_lo, stripe_hi;
-	uint32_t pad;
+	uint32_t pad;        // range partitioning: number of delimiters, else 0
 };
 
 struct Stripe {
@@ -254,12 +254,17 @@ template <typename K, typename V> struct ClassifyLds {
 	static constexpr size_t bytes = kbuf + vbuf + head + small;
 };
 
-template <typename K, typename V>
+// RANGE: the bucket of a key is not a digit but its range among `splitters` (2^width - 1 ascending delimiters,
+// padded with the largest key): bucket p = number of delimiters < key, i.e. range p holds the keys in
+// (delim[p-1], delim[p]] -- the reference's lower-bound range function (binary_search_64, src/msb_64.c:188-204;
+// SIMD form :239-351).  Everything behind the classification (blocks, maps, permutation) is the same.
+template <typename K, typename V, bool RANGE = false>
 __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<V>::value ? 4 : 8) : 1)) void classify_kernel(
 	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, uint8_t *__restrict__ block_map,
 	uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt, uint32_t *__restrict__ lo_off,
-	K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals, uint32_t *__restrict__ nfull)
+	K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals, uint32_t *__restrict__ nfull,
+	const K *__restrict__ splitters = nullptr)
 {
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
@@ -283,11 +288,25 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	uint32_t *loff = hc + kP;    // leftover offsets
 	uint32_t *jobs = loff + kP;  // flush job table: bucket whose buffer goes to slot wslot+g
 	uint32_t *tmp = jobs + L::JOBS; // [0..1] slots claimed per tile (ping-pong), [2..3] buffer-flush jobs, [4..] scan scratch
+	K *spl = reinterpret_cast<K *>(smem + L::bytes); // RANGE only: the delimiters (the launch adds kP keys of LDS)
 
 	const uint32_t tid = threadIdx.x;
 	const Stripe st = stripes[blockIdx.x];
 	const Parent pa = parents[st.parent];
 	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u;
+	if constexpr (RANGE) {
+		if (tid < kP) spl[tid] = tid < pa.pad ? splitters[tid] : ~(K)0; // pa.pad: number of delimiters
+	}
+	// bucket of a key: digit, or number of delimiters below it (branch-free binary search in LDS)
+	auto digit_of = [&](K key, uint32_t sh, uint32_t mk) -> uint32_t {
+		if constexpr (RANGE) {
+			uint32_t p = 0;
+			for (uint32_t step = (mk + 1u) >> 1; step; step >>= 1)
+				if (spl[p + step - 1u] < key) p += step;
+			return p;
+		} else
+			return msd::digit_of(key, sh, mk);
+	};
 
 	if (tid < kP) {
 		meta[tid] = 0;
@@ -1109,6 +1128,10 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	MSD_STAMP_FLUSH(TH / 64);
 }
 
+} // namespace msd
+#include "msd_direct.hpp"
+namespace msd {
+
 // ------------------------------------------------- child geometry per parent
 
 struct ChildArrays {
@@ -1712,14 +1735,14 @@ __global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArr
 __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, ChildArrays ca,
 	uint64_t small_max, uint64_t med_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
 	Segment *__restrict__ small, Segment *__restrict__ small_count, Segment *__restrict__ big, uint32_t big_cap,
-	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out)
+	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out, uint32_t count_n)
 {
 	const Parent pa = parents[blockIdx.x];
 	const uint32_t d = threadIdx.x;
 	if (d >= (1u << pa.width)) return;
 	const uint32_t ci = pa.child_base + d;
 	const uint64_t c = ca.count[ci];
-	if (count_out) count_out[ci] = c;
+	if (count_out && ci < count_n) count_out[ci] = c;
 	if (c <= 1 || pa.shift == 0) return;
 	Segment s;
 	s.start = ca.start[ci];
@@ -2853,6 +2876,48 @@ __global__ void gen_iota_u64_kernel(uint64_t *out, uint64_t n, uint64_t first)
 	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
 		out[i] = first + i;
+}
+
+// ------------------------------------------------------- splitter service
+
+// Random sample of an (unsorted) array: out[i] = keys[mulhi(rand64, n)], as the reference draws its sample
+// (src/msb_64.c:1511-1521, mulhi :178-186) -- with a counter-based generator in place of its MT19937 stream
+// (which it seeds from an uninitialised field).
+template <typename K>
+__global__ __launch_bounds__(256) void sample_kernel(const K *__restrict__ keys, uint64_t n, uint64_t m, uint64_t seed,
+	K *__restrict__ out)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride)
+		out[i] = keys[__umul64hi(splitmix64(seed + i), n)];
+}
+
+// parts-1 equi-depth delimiters of a sorted sample with the reference's duplicate rule (extract_delimiters,
+// src/msb_64.c:1304-1322): pick sample[(uint64)(m / parts * (i+1) - 0.001)]; if more repetitions of the picked
+// value lie at and after the pick than before it (and the value is not 0), use value-1, so that a heavy value
+// does not straddle two ranges.  The reference walks to both ends of the run of equal values; here they are found
+// by binary search (same result: `start` = last index before the run, or 0; `end` = first index behind it).
+template <typename K>
+__global__ __launch_bounds__(256) void splitters_kernel(const K *__restrict__ sample, uint64_t m, uint32_t parts, K *__restrict__ delim)
+{
+	const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i + 1 >= parts) return;
+	const double pct = __ddiv_rn((double)m, (double)parts);
+	const uint64_t idx = (uint64_t)__dsub_rn(__dmul_rn(pct, (double)(i + 1)), 0.001); // (no fused multiply-add: the reference rounds twice)
+	K v = sample[idx];
+	uint64_t lo = 0, hi = idx; // first index holding v
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (sample[mid] < v) lo = mid + 1; else hi = mid;
+	}
+	const uint64_t start = lo ? lo - 1 : 0;
+	uint64_t lo2 = idx, hi2 = m; // first index behind the run
+	while (lo2 < hi2) {
+		const uint64_t mid = (lo2 + hi2) >> 1;
+		if (sample[mid] <= v) lo2 = mid + 1; else hi2 = mid;
+	}
+	if (idx - start < lo2 - idx && v) --v;
+	delim[i] = v;
 }
 
 } // namespace msd

@@ -11,11 +11,15 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 using namespace msd;
 
 #define MSD_VERSION "inplacemsdradixsort_amd 0.2 (gfx950)"
+
+// range partitioning (classify_kernel<.., true>) is built for the key type the multi-GPU path shards: u32 keys
+template <typename K, typename V> constexpr bool kHasRange = std::is_same<K, uint32_t>::value && !has_val<V>::value;
 
 struct PhaseRec {
 	const char *name;
@@ -47,6 +51,7 @@ struct msd_ctx {
 	int direct_mode = 1;
 	uint64_t direct_min = 1ull << 26; // smallest round (elements) it is tried on
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
+	int direct_kernel = 2; // 1: first version of the direct classify kernel (A/B comparisons), 2: msd_direct.hpp
 };
 
 static int fail(msd_ctx *c, int code, const char *fmt, ...)
@@ -235,7 +240,7 @@ static uint32_t pick_width(uint64_t count, uint32_t bits, uint64_t small_max, ui
 
 template <typename K, typename V>
 static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int sm_count, RoundPlan &rp, uint32_t leaf_bits = 0,
-		       uint32_t forced_width = 0)
+		       uint32_t forced_width = 0, uint32_t nsplit = 0)
 {
 	using C = Cfg<K, V>;
 	constexpr uint64_t B = C::B, T = C::T;
@@ -257,7 +262,7 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 		p.shift = s.bits - p.width;
 		p.child_base = rp.nchildren;
 		p.stripe_lo = (uint32_t)rp.stripes.size();
-		p.pad = 0;
+		p.pad = nsplit; // range partitioning: number of delimiters
 		rp.nchildren += 1u << p.width;
 		const uint64_t end = s.start + s.count;
 		const uint64_t a0 = (s.start + B - 1) / B * B; // first aligned position
@@ -417,7 +422,9 @@ static size_t round_bytes_estimate(uint64_t n, int sm_count)
 template <typename K, typename V>
 static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bit,
 		     // single-pass mode (msd_partition_*): one round, caller-chosen digit
-		     bool single_pass, unsigned sp_shift, unsigned sp_width, uint64_t *sp_count)
+		     bool single_pass, unsigned sp_shift, unsigned sp_width, uint64_t *sp_count,
+		     // ... or, instead of a digit, the key's range among nsplit ascending delimiters (msd_partition_by_splitters_*)
+		     const K *splitters = nullptr, uint32_t nsplit = 0)
 {
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
@@ -521,7 +528,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	bool prev_direct = false; // the previous round placed its blocks directly (its digit was evenly spread)
 	while (!cur.empty()) {
 		RoundPlan rp;
-		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits, single_pass ? sp_width : 0u);
+		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits, single_pass ? sp_width : 0u, splitters ? nsplit : 0u);
 		RoundBufs rb;
 		{
 			Bump sz(nullptr);
@@ -567,7 +574,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		// after a direct first round -- from exact counts (a read-only pass).
 		// (the read schedule hands a bucket one slot per tile: with fewer than 256 buckets the tiles
 		// are not filled, so narrower digits keep the streaming kernel unless forced)
-		bool try_direct = c->direct_mode != 0 && rp.round_keys >= c->direct_min;
+		bool try_direct = c->direct_mode != 0 && rp.round_keys >= c->direct_min && !splitters;
 		for (size_t i = 0; i < np && try_direct; ++i) try_direct = rp.parents[i].width == 8 || c->direct_mode == 2;
 		if (try_direct && np > 1) {
 			try_direct = prev_direct && np <= kDirectMaxParents;
@@ -596,10 +603,17 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			phase_mark(c, np == 1 ? "A sample" : "A histogram");
 			direct = *(const uint32_t *)c->pinned == 0 || c->direct_mode == 2; // all parents' children about equally big
 			if (direct) {
-				constexpr size_t direct_lds = DirectLds<K, V>::bytes;
-				hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
-						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
-						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
+				if (c->direct_kernel == 1) {
+					constexpr size_t direct_lds = DirectLds<K, V>::bytes;
+					hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
+							   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
+							   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
+				} else {
+					constexpr size_t direct_lds = Direct2Lds<K, V>::bytes;
+					hipLaunchKernelGGL((classify_direct2_kernel<K, V>), dim3(ns), dim3(Direct2Cfg<K, V>::TH), direct_lds, c->stream,
+							   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
+							   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
+				}
 				HIPCHK(c, hipGetLastError());
 				add_stat(c, "direct_rounds", 1);
 				phase_mark(c, "A classify direct");
@@ -608,9 +622,19 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		prev_direct = direct;
 		if (!direct) {
 			constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
-			hipLaunchKernelGGL((classify_kernel<K, V>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
-					   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
-					   (K *)rb.lo_keys, rb.lo_vals, rb.nfull);
+			bool launched = false;
+			if constexpr (kHasRange<K, V>) {
+				if (splitters) {
+					hipLaunchKernelGGL((classify_kernel<K, V, true>), dim3(ns), dim3(C::TH), classify_lds + kP * sizeof(K), c->stream,
+							   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, splitters);
+					launched = true;
+				}
+			}
+			if (!launched)
+				hipLaunchKernelGGL((classify_kernel<K, V, false>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
+						   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+						   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, (const K *)nullptr);
 			HIPCHK(c, hipGetLastError());
 		}
 		const uint8_t *full_map = direct ? (const uint8_t *)slot_full : (const uint8_t *)nullptr;
@@ -654,7 +678,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				   single_pass ? ~0ull : small_max, (HV || single_pass) ? small_max : std::max<uint64_t>(small_max, kCountMedMax),
 				   small_cap, single_pass ? 0u : count_bits,
 				   rb.next_parents, small, small_count, (HV || single_pass) ? (Segment *)nullptr : big, big_cap, ctr,
-				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr);
+				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr, splitters ? nsplit + 1u : nc);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "C cleanup");
 
@@ -802,12 +826,17 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 {
-	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_kernel<K, V>),
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_kernel<K, V, false>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
+	if constexpr (kHasRange<K, V>)
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_kernel<K, V, true>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ClassifyLds<K, V>::bytes + kP * sizeof(K))));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DirectLds<K, V>::bytes));
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct2_kernel<K, V>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Direct2Lds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
@@ -845,7 +874,8 @@ int msd_create(msd_ctx **out, int device, void *stream)
 	}
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->sm_count = prop.multiProcessorCount;
-	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switch for benchmarks
+	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switches for benchmarks
+	if (getenv("MSD_DIRECT_KERNEL")) c->direct_kernel = atoi(getenv("MSD_DIRECT_KERNEL")) == 1 ? 1 : 2;
 	int rc = set_lds_attrs<uint32_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, uint64_t>(c);
@@ -945,6 +975,48 @@ int msd_partition_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, un
 	if (!c) return MSD_EINVAL;
 	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
 	return sort_impl<uint64_t, uint64_t>(c, k, r, n, 64, true, shift, rb, cnt);
+}
+
+// ---- splitter service (reference: sampling src/msb_64.c:1511-1521, extract_delimiters :1304-1322, range function :188-204)
+
+int msd_sample_u32(msd_ctx *c, const uint32_t *k, uint64_t n, uint64_t m, uint64_t seed, uint32_t *out)
+{
+	if (!c) return MSD_EINVAL;
+	if (m && (!k || !out || n == 0)) return fail(c, MSD_EINVAL, "sample: null pointer or empty input");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (m == 0) return MSD_OK;
+	const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (m + 255) / 256);
+	hipLaunchKernelGGL((sample_kernel<uint32_t>), dim3(grid), dim3(256), 0, c->stream, k, n, m, seed, out);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
+int msd_splitters_u32(msd_ctx *c, const uint32_t *sorted_sample, uint64_t m, unsigned parts, uint32_t *delims)
+{
+	if (!c) return MSD_EINVAL;
+	if (parts < 1 || parts > 256) return fail(c, MSD_EINVAL, "splitters: parts must be 1..256");
+	if (parts == 1) return MSD_OK;
+	if (!sorted_sample || !delims || m == 0) return fail(c, MSD_EINVAL, "splitters: null pointer or empty sample");
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL((splitters_kernel<uint32_t>), dim3(1), dim3(256), 0, c->stream, sorted_sample, m, parts, delims);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
+int msd_partition_by_splitters_u32(msd_ctx *c, uint32_t *k, uint64_t n, const uint32_t *delims, unsigned parts, uint64_t *cnt)
+{
+	if (!c) return MSD_EINVAL;
+	if (parts < 1 || parts > 256) return fail(c, MSD_EINVAL, "partition_by_splitters: parts must be 1..256");
+	if (parts > 1 && !delims) return fail(c, MSD_EINVAL, "partition_by_splitters: null delimiters");
+	if (cnt) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) * parts, c->stream));
+	if (parts == 1) { // one range: nothing moves
+		if (cnt) HIPCHK(c, hipMemcpy(cnt, &n, sizeof n, hipMemcpyHostToDevice));
+		return MSD_OK;
+	}
+	unsigned width = 1;
+	while ((1u << width) < parts) ++width;
+	// one in-place round whose buckets are the ranges (parts - 1 delimiters; the buckets beyond `parts` stay empty)
+	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, 32, true, 0, width, cnt, delims, parts - 1);
 }
 
 } // extern "C"
@@ -1110,6 +1182,9 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "direct_min")) {
 		if (value < 1) return fail(c, MSD_EINVAL, "direct_min must be positive");
 		c->direct_min = (uint64_t)value;
+	} else if (!strcmp(name, "direct_kernel")) {
+		if (value < 1 || value > 2) return fail(c, MSD_EINVAL, "direct_kernel must be 1 or 2");
+		c->direct_kernel = (int)value;
 	} else if (!strcmp(name, "direct_min_parent")) {
 		if (value < 1) return fail(c, MSD_EINVAL, "direct_min_parent must be positive");
 		c->direct_min_parent = (uint64_t)value;
