@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
 # diagnostic build with in-kernel cycle stamps (tools/stamps_run.py); never what tests or bench.py load
 STAMPS_LIB = os.path.join(HERE, "libinpmsdradix_hip_stamps.so")
 SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
-DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
+DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_count16.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
                   os.path.join("..", "..", "include", "msb_64.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wno-unused-result"]
@@ -48,8 +48,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-def build_stamps(extra=(), out: str = STAMPS_LIB) -> str:
-    cmd = [_hipcc(), *FLAGS, "-DMSD_STAMPS", *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
+def build_stamps(extra=(), out: str = STAMPS_LIB, which: int = 1) -> str:
+    """which: 1 = the direct classify kernels, 2 = count_place_kernel carry the stamps."""
+    cmd = [_hipcc(), *FLAGS, f"-DMSD_STAMPS={which}", *extra, *[os.path.join(CSRC, s) for s in SOURCES], "-o", out]
     subprocess.check_call(cmd)
     return out
 

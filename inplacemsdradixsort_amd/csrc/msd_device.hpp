@@ -109,40 +109,54 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t count_ticket2; // work ticket of count_walk_kernel
 	uint32_t nevict;        // per round: side-store blocks handed out for evictions
 	uint32_t leaf_ticket[2]; // work tickets of the two leaf_count_sort launches
+	uint32_t count_ticket3;  // work ticket of count_place16_kernel
+	uint32_t nslow16;        // segments count_place16_kernel left to count_place_kernel
 };
+static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used for 64-bit atomics");
 
 // ---------------------------------------------------------------- diagnostics
 // -DMSD_STAMPS (tools/stamps_build.sh, never the shipped library): wave 0 (a "bucket wave") and the last wave of
 // every classify_direct workgroup add the shader cycles they spend in each section of the tile loop to
 // g_stamps[which wave][section]; read back with msd_debug_stamps().
-#ifdef MSD_STAMPS
+#ifdef MSD_STAMPS // = 1: classify_direct kernels, 2: count_place_kernel
 __device__ unsigned long long g_stamps[2][16];
-#define MSD_STAMP_DECL unsigned long long st_acc[12] = {}, st_last = 0
-#define MSD_STAMP_START()                                                                      \
-	do {                                                                                    \
-		__builtin_amdgcn_sched_barrier(0);                                              \
-		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); \
-		__builtin_amdgcn_sched_barrier(0);                                              \
+#define MSD_STAMP_DECL(id)                          \
+	constexpr bool kStampThis = MSD_STAMPS == (id); \
+	unsigned long long st_acc[12] = {}, st_last = 0
+#define MSD_STAMP_START()                                                                              \
+	do {                                                                                            \
+		if constexpr (kStampThis) {                                                             \
+			__builtin_amdgcn_sched_barrier(0);                                              \
+			asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory"); \
+			__builtin_amdgcn_sched_barrier(0);                                              \
+		}                                                                                       \
 	} while (0)
-#define MSD_STAMP(i)                                                                            \
-	do {                                                                                    \
-		unsigned long long now_;                                                        \
-		__builtin_amdgcn_sched_barrier(0);                                              \
-		asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");    \
-		__builtin_amdgcn_sched_barrier(0);                                              \
-		st_acc[i] += now_ - st_last;                                                    \
-		st_last = now_;                                                                 \
+#define MSD_STAMP(i)                                                                                    \
+	do {                                                                                            \
+		if constexpr (kStampThis) {                                                             \
+			unsigned long long now_;                                                        \
+			__builtin_amdgcn_sched_barrier(0);                                              \
+			asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");    \
+			__builtin_amdgcn_sched_barrier(0);                                              \
+			st_acc[i] += now_ - st_last;                                                    \
+			st_last = now_;                                                                 \
+		}                                                                                       \
 	} while (0)
-#define MSD_STAMP_TICK(i) st_acc[i] += 1
-#define MSD_STAMP_FLUSH(nwaves)                                                                 \
-	do {                                                                                    \
-		const unsigned wv_ = threadIdx.x >> 6;                                          \
-		if ((threadIdx.x & 63) == 0 && (wv_ == 0 || wv_ == (nwaves) - 1)) {            \
-			for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[wv_ ? 1 : 0][i_], st_acc[i_]); \
-		}                                                                               \
+#define MSD_STAMP_TICK(i)                            \
+	do {                                         \
+		if constexpr (kStampThis) st_acc[i] += 1; \
+	} while (0)
+#define MSD_STAMP_FLUSH(nwaves)                                                                         \
+	do {                                                                                            \
+		if constexpr (kStampThis) {                                                             \
+			const unsigned wv_ = threadIdx.x >> 6;                                          \
+			if ((threadIdx.x & 63) == 0 && (wv_ == 0 || wv_ == (nwaves) - 1)) {            \
+				for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&g_stamps[wv_ ? 1 : 0][i_], st_acc[i_]); \
+			}                                                                               \
+		}                                                                                       \
 	} while (0)
 #else
-#define MSD_STAMP_DECL
+#define MSD_STAMP_DECL(id)
 #define MSD_STAMP_START() do {} while (0)
 #define MSD_STAMP(i) do {} while (0)
 #define MSD_STAMP_TICK(i) do {} while (0)
@@ -909,7 +923,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	bool okB = load_tile(kregB, vregB);
 	uint32_t par = 0;
 
-	MSD_STAMP_DECL;
+	MSD_STAMP_DECL(1);
 	MSD_STAMP_START();
 	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1], bool &okc, uint32_t &nc) {
 		MSD_STAMP(9); // flush of the previous tile + loop overhead
@@ -1805,8 +1819,10 @@ struct CountLds {
 
 template <typename K>
 __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict__ keys,
-	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ slow, Counters *__restrict__ ctr)
+	const Segment *__restrict__ segs, uint32_t nsegs_host, const uint32_t *__restrict__ nsegs_dev,
+	Segment *__restrict__ slow, Counters *__restrict__ ctr)
 {
+	const uint32_t nsegs = nsegs_dev ? *nsegs_dev : nsegs_host; // (the list may come from count_place16_kernel)
 	// keys per thread held in registers: a little more than 2^14 / 1024, the typical segment
 	constexpr int PF = sizeof(K) == 4 ? 17 : 9;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1834,12 +1850,16 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 		}
 	};
 	prefetch(sg);
+	MSD_STAMP_DECL(2);
+	MSD_STAMP_START();
 	for (;;) {
 		const uint32_t n = (uint32_t)sg.count;
 		const uint32_t nv = 1u << sg.bits, mask = nv - 1u;
 		const uint32_t nwords = nv >= 4 ? nv / 4 : 1;
 		K *seg = keys + sg.start;
 		const bool in_regs = n <= (uint32_t)(PF * kCountTh);
+		MSD_STAMP(9);
+		MSD_STAMP_TICK(11);
 
 		if (in_regs)
 			for (uint32_t j = tid; j < cw_at(nwords) + 1; j += kCountTh) cw[j] = 0;
@@ -1848,7 +1868,9 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 			*crowded = 0;
 			*hi_l = pk[0] & ~(K)mask; // common prefix of the whole segment
 		}
+		MSD_STAMP(0); // clear
 		__syncthreads();
+		MSD_STAMP(1);
 		// value (low 16 bits) | rank among equal keys, later | output position (high 16 bits)
 		uint32_t rk[PF];
 		if (in_regs) {
@@ -1862,7 +1884,9 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 				}
 			}
 		}
+		MSD_STAMP(2); // fetch-adds (incl. the wait for the keys)
 		__syncthreads();
+		MSD_STAMP(3);
 		const uint32_t nxt = *nexti;
 		const K hi = *hi_l;
 		// ---- exclusive prefix of the counters; thread t owns words [t*wpt, (t+1)*wpt), wpt <= 16
@@ -1878,6 +1902,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 		if (tot > 255u) *crowded = 1;
 		const uint32_t inc = wave_incl_scan(tot);
 		if (lane == 63) wtot[w] = inc;
+		MSD_STAMP(4); // byte sums + wave scan
 		__syncthreads();
 		uint32_t pos = inc - tot, all = 0;
 #pragma unroll 2
@@ -1888,6 +1913,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 		}
 		// a byte that overflowed carried into its neighbour: the sum of all bytes then falls short of n
 		const bool ok = in_regs && all == n && *crowded == 0;
+		MSD_STAMP(5); // barrier + block scan
 		if (ok) {
 			uint32_t run = 0;
 			if (w0 < nwords) {
@@ -1899,6 +1925,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 				}
 			}
 			tbase[tid] = pos;
+			MSD_STAMP(6); // prefix inside the thread's words
 			__syncthreads();
 			const uint32_t lgw = (uint32_t)__builtin_ctz(wpt);
 #pragma unroll
@@ -1909,6 +1936,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 					rk[u] += (tbase[wi >> lgw] + ((cw[cw_at(wi)] >> ((v & 3u) * 8u)) & 0xFFu)) << 16;
 				}
 			}
+			MSD_STAMP(7); // positions
 			__syncthreads(); // counters and bases are dead: everything up to the stage's end is the output buffer
 #pragma unroll
 			for (int u = 0; u < PF; ++u) {
@@ -1916,6 +1944,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 				if (tid < left) out[rk[u] >> 16] = hi | (K)(rk[u] & 0xFFFFu);
 			}
 			__syncthreads();
+			MSD_STAMP(8); // barrier + output into LDS + barrier
 		} else if (tid == 0)
 			slow[atomicAdd(&ctr->nslow, 1u)] = sg; // untouched
 		Segment nsg = sg;
@@ -1926,10 +1955,12 @@ __global__ __launch_bounds__(kCountTh, 8) void count_place_kernel(K *__restrict_
 		if (ok) {
 			for (uint32_t i = tid; i < n; i += kCountTh) seg[i] = out[i];
 		}
+		MSD_STAMP(10); // prefetch issue + store
 		if (nxt >= nsegs) break;
 		sg = nsg;
 		__syncthreads(); // the output buffer is cleared next
 	}
+	MSD_STAMP_FLUSH(kCountTh / 64);
 }
 
 template <typename K>
@@ -2060,6 +2091,10 @@ __global__ __launch_bounds__(kCountTh, 8) void count_walk_kernel(K *__restrict__
 		__syncthreads(); // nexti / hi_l / wtot are rewritten next
 	}
 }
+
+} // namespace msd
+#include "msd_count16.hpp"
+namespace msd {
 
 // ------------------------------------------- counting leaf (keys or tuples)
 

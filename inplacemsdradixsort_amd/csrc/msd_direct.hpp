@@ -322,7 +322,7 @@ __global__ __launch_bounds__((Direct2Cfg<K, V>::TH), (Direct2Cfg<K, V>::WPE)) vo
 	uint32_t par = 0;
 	__syncthreads();
 
-	MSD_STAMP_DECL;
+	MSD_STAMP_DECL(1);
 	MSD_STAMP_START();
 	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1], uint32_t &okc, uint32_t &nc) {
 		MSD_STAMP(9); // refill of the previous tile + loop overhead

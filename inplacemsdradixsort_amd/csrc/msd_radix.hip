@@ -51,6 +51,7 @@ struct msd_ctx {
 	int direct_mode = 1;
 	uint64_t direct_min = 1ull << 26; // smallest round (elements) it is tried on
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
+	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
 	int direct_kernel = 2; // 1: first version of the direct classify kernel (A/B comparisons), 2: msd_direct.hpp
 };
 
@@ -719,12 +720,26 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		if (ncount_host && !single_pass) {
 			// persistent workgroups (two per CU fit the LDS), segments handed out by ticket; what the fast
 			// kernel cannot place directly is queued (in the round slab, dead by now) for the walking kernel
-			int rcs = slab_reserve(c, (size_t)ncount_host * sizeof(Segment) + 4096);
+			int rcs = slab_reserve(c, 2 * (size_t)ncount_host * sizeof(Segment) + 4096);
 			if (rcs) return rcs;
-			Segment *slow = reinterpret_cast<Segment *>(c->slab);
+			Segment *slow = reinterpret_cast<Segment *>(c->slab), *rej16 = slow + ncount_host;
 			const uint32_t count_grid = std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count * 2);
-			hipLaunchKernelGGL((count_place_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
-					   keys, small_count, ncount_host, slow, ctr);
+			if constexpr (sizeof(K) == 4) {
+				// u32 keys with 16 open bits (what the planner aims for): the specialised kernel first, the general one
+				// takes what that leaves (other bit counts, long or crowded segments)
+				// (it pays for segments of about 2^14 keys -- 2^30-key inputs; on shorter ones the per-segment work on the
+				// 2^16 counters dominates and 1024-thread workgroups hide its latency better: 1.15 vs 1.44 ms at 2^28)
+				if (c->count16 == 2 || (c->count16 == 1 && n / ncount_host >= 12000)) {
+					hipLaunchKernelGGL(count_place16_kernel, dim3(count_grid), dim3(kC16Th), kC16Lds, c->stream,
+							   keys, small_count, ncount_host, rej16, ctr, n);
+					hipLaunchKernelGGL((count_place_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
+							   keys, rej16, 0u, (const uint32_t *)&ctr->nslow16, slow, ctr);
+				} else
+					hipLaunchKernelGGL((count_place_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
+							   keys, small_count, ncount_host, (const uint32_t *)nullptr, slow, ctr);
+			} else
+				hipLaunchKernelGGL((count_place_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
+						   keys, small_count, ncount_host, (const uint32_t *)nullptr, slow, ctr);
 			hipLaunchKernelGGL((count_walk_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
 					   keys, slow, &ctr->nslow, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
 			HIPCHK(c, hipGetLastError());
@@ -840,6 +855,9 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
+		if constexpr (sizeof(K) == 4)
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_place16_kernel),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_place_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_walk_kernel<K>),
@@ -875,6 +893,7 @@ int msd_create(msd_ctx **out, int device, void *stream)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->sm_count = prop.multiProcessorCount;
 	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switches for benchmarks
+	if (getenv("MSD_COUNT16")) c->count16 = atoi(getenv("MSD_COUNT16")); // 0 off, 1 by segment size, 2 always
 	if (getenv("MSD_DIRECT_KERNEL")) c->direct_kernel = atoi(getenv("MSD_DIRECT_KERNEL")) == 1 ? 1 : 2;
 	int rc = set_lds_attrs<uint32_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, NoVal>(c);
@@ -1182,6 +1201,9 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "direct_min")) {
 		if (value < 1) return fail(c, MSD_EINVAL, "direct_min must be positive");
 		c->direct_min = (uint64_t)value;
+	} else if (!strcmp(name, "count16")) {
+		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
+		c->count16 = (int)value;
 	} else if (!strcmp(name, "direct_kernel")) {
 		if (value < 1 || value > 2) return fail(c, MSD_EINVAL, "direct_kernel must be 1 or 2");
 		c->direct_kernel = (int)value;

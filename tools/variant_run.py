@@ -62,6 +62,8 @@ out = {"lib": name, "kind": kind, "logn": logn, "ms": [round(x, 3) for x in time
        "stats": ctx.stats()}
 if hasattr(L, "msd_debug_stamps"):
     NAMES = ["scatter", "B1", "bookkeeping", "B2", "flush", "select", "waiting-keys", "B3", "-", "refill+loop", "epilogue", "tiles"]
+    if name.startswith("cstamps"):  # count_place_kernel sections
+        NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
     L.msd_debug_stamps.argtypes = [C.POINTER(C.c_uint64)]
     buf = (C.c_uint64 * 32)()
     ctx.set_profiling(False)
@@ -74,7 +76,7 @@ if hasattr(L, "msd_debug_stamps"):
     for w, label in ((0, "wave0"), (1, "last_wave")):
         v = [int(buf[w * 16 + i]) for i in range(12)]
         tiles = max(1, v[11])
-        out[label] = {NAMES[i]: round(v[i] / tiles, 1) for i in range(11) if NAMES[i] != "-"}
-        out[label]["cycles_per_tile"] = round(sum(v[:10]) / tiles, 1)
+        out[label] = {f"{i}:{NAMES[i]}": round(v[i] / tiles, 1) for i in range(11) if NAMES[i] != "-"}
+        out[label]["cycles_per_tile"] = round(sum(v[:11]) / tiles, 1)
         out[label]["tiles"] = v[11]
 print(json.dumps(out))
