@@ -278,8 +278,12 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	const Parent *__restrict__ parents, uint8_t *__restrict__ block_map,
 	uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt, uint32_t *__restrict__ lo_off,
 	K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals, uint32_t *__restrict__ nfull,
-	const K *__restrict__ splitters = nullptr)
+	const K *__restrict__ splitters = nullptr,
+	// launched behind a direct-placement attempt: runs only if that declined (Counters::direct_uneven != 0) -- the
+	// decision stays on the device, the host does not wait for it
+	const uint32_t *__restrict__ run_if_nonzero = nullptr)
 {
+	if (run_if_nonzero && *run_if_nonzero == 0) return;
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
 	constexpr int B = C::B, T = C::T, TH = C::TH;
@@ -758,8 +762,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plans, uint8_t *__restrict__ block_map,
 	uint8_t *__restrict__ slot_full, uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt,
 	uint32_t *__restrict__ lo_off, K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals,
-	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr)
+	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr, uint32_t force)
 {
+	if (!force && ctr->direct_uneven) return; // the plan declined: the streaming kernel behind this launch runs instead
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
 	constexpr int B = C::B, TH = C::TH;
@@ -1255,10 +1260,12 @@ template <bool SCATTER>
 __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, const uint8_t *__restrict__ block_map,
 	const uint32_t *__restrict__ nfull, ChildArrays ca, ListEntry *__restrict__ list,
-	ListEntry *__restrict__ holes, Counters *__restrict__ ctr, const uint8_t *__restrict__ slot_full)
+	ListEntry *__restrict__ holes, Counters *__restrict__ ctr, const uint8_t *__restrict__ slot_full_arg, uint32_t force)
 {
 	// slot_full == nullptr: a stripe's first nfull slots hold blocks (streaming classify);
-	// otherwise a byte per slot says whether it holds a block (direct placement)
+	// otherwise a byte per slot says whether it holds a block (direct placement; the map counts only if the
+	// direct kernel ran: the plan did not decline, or the mode forces it)
+	const uint8_t *slot_full = (slot_full_arg && (force || ctr->direct_uneven == 0)) ? slot_full_arg : nullptr;
 	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP], s_base[2][kP];
 	// kSlotParts workgroups share a stripe (each a contiguous part of its slots): the sweeps are short
 	// latency-bound loops, so more, smaller workgroups finish sooner; counts and list ranges are

@@ -56,8 +56,9 @@ __global__ __launch_bounds__((Direct2Cfg<K, V>::TH), (Direct2Cfg<K, V>::WPE)) vo
 	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plans, uint8_t *__restrict__ block_map,
 	uint8_t *__restrict__ slot_full, uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt,
 	uint32_t *__restrict__ lo_off, K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals,
-	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr)
+	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr, uint32_t force)
 {
+	if (!force && ctr->direct_uneven) return; // the plan declined: the streaming kernel behind this launch runs instead
 	using C = Cfg<K, V>;
 	using D = Direct2Cfg<K, V>;
 	using L = Direct2Lds<K, V>;

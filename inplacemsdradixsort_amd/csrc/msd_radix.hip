@@ -570,7 +570,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		phase_mark(c, "plan+upload");
 
 		// ---- A: classify (histogram falls out of it)
-		bool direct = false;
+		bool tried_direct = false;
 		// Direct placement (DESIGN.md section 2, A'): the first round from a sample, later rounds -- only
 		// after a direct first round -- from exact counts (a read-only pass).
 		// (the read schedule hands a bucket one slot per tile: with fewer than 256 buckets the tiles
@@ -599,52 +599,52 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			} else
 				hipLaunchKernelGGL((direct_hist_kernel<K>), dim3(ns), dim3(1024), 0, c->stream, (const K *)keys, rb.stripes, rb.parents, rb.plans);
 			hipLaunchKernelGGL((direct_plan_kernel<B>), dim3(np), dim3(256), 0, c->stream, rb.parents, rb.plans, ctr);
-			HIPCHK(c, hipMemcpyAsync(c->pinned, &ctr->direct_uneven, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(c, hipStreamSynchronize(c->stream));
 			phase_mark(c, np == 1 ? "A sample" : "A histogram");
-			direct = *(const uint32_t *)c->pinned == 0 || c->direct_mode == 2; // all parents' children about equally big
-			if (direct) {
-				if (c->direct_kernel == 1) {
-					constexpr size_t direct_lds = DirectLds<K, V>::bytes;
-					hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
-							   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
-							   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
-				} else {
-					constexpr size_t direct_lds = Direct2Lds<K, V>::bytes;
-					hipLaunchKernelGGL((classify_direct2_kernel<K, V>), dim3(ns), dim3(Direct2Cfg<K, V>::TH), direct_lds, c->stream,
-							   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
-							   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr);
-				}
-				HIPCHK(c, hipGetLastError());
-				add_stat(c, "direct_rounds", 1);
-				phase_mark(c, "A classify direct");
+			// The plan's verdict (Counters::direct_uneven: some parent's children are too unequal, or its keys come in
+			// runs) stays on the device: the direct kernel returns at once if it is non-zero, the streaming kernel
+			// launched behind it if it is zero.  The host learns it with the round's summary.
+			tried_direct = true;
+			const uint32_t force = c->direct_mode == 2 ? 1u : 0u;
+			if (c->direct_kernel == 1) {
+				constexpr size_t direct_lds = DirectLds<K, V>::bytes;
+				hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
+						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
+						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr, force);
+			} else {
+				constexpr size_t direct_lds = Direct2Lds<K, V>::bytes;
+				hipLaunchKernelGGL((classify_direct2_kernel<K, V>), dim3(ns), dim3(Direct2Cfg<K, V>::TH), direct_lds, c->stream,
+						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
+						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr, force);
 			}
+			HIPCHK(c, hipGetLastError());
+			phase_mark(c, "A classify direct");
 		}
-		prev_direct = direct;
-		if (!direct) {
+		if (!tried_direct || c->direct_mode != 2) {
 			constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
+			const uint32_t *run_if = tried_direct ? (const uint32_t *)&ctr->direct_uneven : (const uint32_t *)nullptr;
 			bool launched = false;
 			if constexpr (kHasRange<K, V>) {
 				if (splitters) {
 					hipLaunchKernelGGL((classify_kernel<K, V, true>), dim3(ns), dim3(C::TH), classify_lds + kP * sizeof(K), c->stream,
 							   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
-							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, splitters);
+							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, splitters, run_if);
 					launched = true;
 				}
 			}
 			if (!launched)
 				hipLaunchKernelGGL((classify_kernel<K, V, false>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
 						   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
-						   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, (const K *)nullptr);
+						   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, (const K *)nullptr, run_if);
 			HIPCHK(c, hipGetLastError());
 		}
-		const uint8_t *full_map = direct ? (const uint8_t *)slot_full : (const uint8_t *)nullptr;
+		const uint8_t *full_map = tried_direct ? (const uint8_t *)slot_full : (const uint8_t *)nullptr;
+		const uint32_t force_map = c->direct_mode == 2 ? 1u : 0u;
 		phase_mark(c, "A classify");
 
 		// ---- block metadata: child geometry, misplaced-block lists, holes
 		hipLaunchKernelGGL((child_scan_kernel<B>), dim3(np), dim3(1024), 0, c->stream, rb.parents, rb.fb, rb.lo_cnt, rb.lo_dst, rb.ca);
 		hipLaunchKernelGGL((slot_classify_kernel<false>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
-				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
+				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map, force_map);
 		hipLaunchKernelGGL(list_prepare_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr,
 				   (uint32_t)std::min<uint64_t>(rp.nslots, 0xFFFFFFFFu), (uint32_t)(2 * nc + kMinChains));
 		{
@@ -652,7 +652,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			if (rc) return rc;
 		}
 		hipLaunchKernelGGL((slot_classify_kernel<true>), dim3(ns * kSlotParts), dim3(256), 0, c->stream, rb.stripes, rb.parents,
-				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map);
+				   block_map, rb.nfull, rb.ca, rb.list, rb.holes, ctr, full_map, force_map);
 		// per child: up to 64 waves when there are few children, one thread when there are very many
 		const uint32_t evict_waves = nc > 16384 ? 0u : (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, 16384 / nc));
 		const unsigned evict_grid = evict_waves ? (unsigned)(((uint64_t)nc * evict_waves + 3) / 4) : (unsigned)((nc + 255) / 256);
@@ -683,12 +683,24 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "C cleanup");
 
-		// ---- round summary + next parents back to the host (which plans the next round)
+		// ---- round summary + next parents back to the host (which plans the next round): ONE synchronisation; the
+		// first kReadAhead next parents travel with the counters (more than that only on the odd input: fetched then)
+		constexpr size_t kReadAhead = 2048, kSegOff = 256;
+		const size_t np_cap = rp.round_keys / (small_max + 1) + 2, ahead = single_pass ? 0 : std::min(np_cap, kReadAhead);
+		{
+			int rc = pinned_reserve(c, kSegOff + kReadAhead * sizeof(Segment));
+			if (rc) return rc;
+		}
 		Counters hc;
 		HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+		if (ahead)
+			HIPCHK(c, hipMemcpyAsync((char *)c->pinned + kSegOff, rb.next_parents, ahead * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(&hc, c->pinned, sizeof hc);
 		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations", round, hc.errors);
+		const bool direct = tried_direct && (hc.direct_uneven == 0 || c->direct_mode == 2);
+		if (direct) add_stat(c, "direct_rounds", 1);
+		prev_direct = direct;
 		nsmall_host = hc.nsmall;
 		ncount_host = hc.ncount;
 		nbig_host = hc.nbig;
@@ -702,11 +714,15 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		cur.clear();
 		if (single_pass) break;
 		if (hc.next_parents) {
-			int rc = pinned_reserve(c, (size_t)hc.next_parents * sizeof(Segment));
-			if (rc) return rc;
-			HIPCHK(c, hipMemcpyAsync(c->pinned, rb.next_parents, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			cur.assign((Segment *)c->pinned, (Segment *)c->pinned + hc.next_parents);
+			if (hc.next_parents <= ahead)
+				cur.assign((Segment *)((char *)c->pinned + kSegOff), (Segment *)((char *)c->pinned + kSegOff) + hc.next_parents);
+			else {
+				int rc = pinned_reserve(c, (size_t)hc.next_parents * sizeof(Segment));
+				if (rc) return rc;
+				HIPCHK(c, hipMemcpyAsync(c->pinned, rb.next_parents, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+				HIPCHK(c, hipStreamSynchronize(c->stream));
+				cur.assign((Segment *)c->pinned, (Segment *)c->pinned + hc.next_parents);
+			}
 			// atomic appends arrive in any order; make the plan deterministic
 			std::sort(cur.begin(), cur.end(), [](const Segment &a, const Segment &b) { return a.start < b.start; });
 		}

@@ -5,19 +5,27 @@ holds a shard of keys in HBM.  Like the reference's NUMA phase -- contiguous key
 ranges per node (numa_dest, src/msb_64.c:1596-1607), blocks balanced across nodes
 (:1952-1997), then purely local sorting (:2200-2255) -- the distributed sort is:
 
-  1. one in-place top-digit pass on every rank (``engine.partition``): buckets end up
-     contiguous in ascending digit order, so the slice for destination rank d
-     (digits [d*256/G, (d+1)*256/G)) is already packed for sending;
-  2. a G x G count exchange and ONE all-to-all(v) of the keys;
-  3. each rank sorts what it received; all its keys share the top log2(G) bits, which
-     are passed on as ``end_bit`` (the reference passes bits=58 after its 6-bit split,
-     src/msb_64.c:2242).
+  1. one in-place partition pass on every rank: buckets end up contiguous in
+     ascending order, so the slice for destination rank d is already packed for sending.
+     Uniform keys: the top digit (``engine.partition``), destination = top log2(G) bits.
+     Skewed keys: sampled splitters (``sort_sharded_u32_sampled``), destination = range.
+  2. the G x G send matrix is all-gathered (every rank learns every rank's total, so a
+     receive buffer that is too small fails on ALL ranks, not on one) and ONE
+     all-to-all(v) moves the keys;
+  3. each rank sorts what it received; with the radix split all its keys share the top
+     log2(G) bits, which are passed on as ``end_bit`` (the reference passes bits=58 after
+     its 6-bit split, src/msb_64.c:2242).
 
 ``engine`` is an :class:`inplacemsdradixsort_amd.MsdContext`; the CPU gloo tests pass a
-stand-in with the same three methods to exercise the exchange logic without a GPU.
+stand-in with the same methods to exercise the exchange logic without a GPU.
 The receive buffer needs slack over n/G under skew (the reference's ``fudge``).
 """
 from __future__ import annotations
+
+
+class ReceiveOverflow(RuntimeError):
+    """Some rank's receive buffer cannot take its range; raised on EVERY rank (the decision is made
+    from the all-gathered send matrix, before the data exchange, so no rank is left in a collective)."""
 
 
 def _log2(g: int) -> int:
@@ -27,24 +35,40 @@ def _log2(g: int) -> int:
     return b
 
 
+def _rank(dist, group=None) -> int:
+    return int(dist.get_rank(group)) if group is not None else int(dist.get_rank())
+
+
+def exchange_counts(dist, send, capacity: int, world: int, group=None):
+    """All ranks learn the whole G x G send matrix and every rank's receive capacity
+    (one all-gather of G+1 int64 per rank).  Returns (send_list, recv_list) of this rank;
+    raises :class:`ReceiveOverflow` on every rank if any rank's total exceeds its capacity."""
+    import torch
+    row = torch.cat([send.to(torch.int64), torch.tensor([capacity], dtype=torch.int64, device=send.device)])
+    rows = [torch.empty_like(row) for _ in range(world)]
+    dist.all_gather(rows, row, group=group)
+    mat = torch.stack(rows).cpu()                                # [sender, destination | capacity]: one D2H
+    totals, caps = mat[:, :world].sum(dim=0), mat[:, world]
+    over = [(r, int(totals[r]), int(caps[r])) for r in range(world) if int(totals[r]) > int(caps[r])]
+    if over:
+        raise ReceiveOverflow("receive buffer too small on rank(s) " +
+                              ", ".join(f"{r}: {t} keys for capacity {c}" for r, t, c in over) +
+                              " (raise the slack -- the reference's fudge -- or use sort_sharded_u32_sampled)")
+    me = _rank(dist, group)
+    return mat[me, :world].tolist(), mat[:, me].tolist()
+
+
 def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None):
     """Sorts the union of all ranks' ``keys`` (int32 tensors holding u32 bit patterns).
     Returns this rank's sorted range as a view of ``recv``; rank r's range precedes rank r+1's."""
-    import torch
     lg = _log2(world)
     if world == 1:
         engine.sort_u32(keys)
         return keys
     counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
     send = counts.view(world, 256 // world).sum(dim=1)           # keys per destination rank
-    got = torch.empty_like(send)
-    dist.all_to_all_single(got, send, group=group)               # count exchange
-    send_l, got_l = send.tolist(), got.tolist()
-    total = int(sum(got_l))
-    if total > recv.numel():
-        raise RuntimeError(f"receive buffer too small: {total} keys for capacity {recv.numel()} "
-                           "(raise the slack, the reference's fudge)")
-    out = recv[:total]
+    send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
+    out = recv[:int(sum(got_l))]
     dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
     engine.sort_u32(out, end_bit=32 - lg)
     return out
@@ -59,8 +83,8 @@ class ShardedSorter:
     RCCL's stream (xGMI) while the compute stream sorts shard s-1 -- the exchange is as long as a
     local sort, so hiding it is what weak scaling needs.  ``recv_bufs``: at least two buffers (one
     per exchange in flight plus the one being sorted); the tensor returned by ``collect`` is a view
-    of one of them and is overwritten two submissions later.  ``keys`` must stay untouched until the
-    matching ``collect`` returns.
+    of one of them and is overwritten ``len(recv_bufs)`` submissions later.  ``keys`` must stay
+    untouched until the matching ``collect`` returns.
     """
 
     def __init__(self, engine, dist, world: int, recv_bufs, group=None):
@@ -81,7 +105,6 @@ class ShardedSorter:
             return None
 
     def submit(self, keys) -> None:
-        import torch
         if self.world == 1:
             self._pending.append((keys, None, keys))
             return
@@ -89,16 +112,10 @@ class ShardedSorter:
             raise RuntimeError("collect() before submitting more shards than there are receive buffers")
         counts = self.engine.partition(keys, 24, 8)
         send = counts.view(self.world, 256 // self.world).sum(dim=1)
-        got = torch.empty_like(send)
-        self.dist.all_to_all_single(got, send, group=self.group)
-        send_l, got_l = send.tolist(), got.tolist()
-        total = int(sum(got_l))
         recv = self.recv[self._slot]
+        send_l, got_l = exchange_counts(self.dist, send, recv.numel(), self.world, self.group)  # raises on all ranks
         self._slot = (self._slot + 1) % len(self.recv)
-        if total > recv.numel():
-            raise RuntimeError(f"receive buffer too small: {total} keys for capacity {recv.numel()} "
-                               "(raise the slack, the reference's fudge)")
-        out = recv[:total]
+        out = recv[:int(sum(got_l))]
         self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), keys))
 
     def collect(self):
@@ -112,48 +129,49 @@ class ShardedSorter:
         return len(self._pending)
 
 
-def sort_sharded_u32_sampled(engine, keys, recv, dist, world: int, group=None, sample_per_rank: int = 65536):
-    """Skew-robust variant (the reference's own scheme, src/msb_64.c:1511-1564): every rank sorts
-    its shard, contributes an equidistant sample of it, all ranks derive the same world-1 equi-depth
-    splitters with the reference's duplicate rule (:func:`splitters_equi_depth`), the sorted shard
-    is cut at the splitters (range p = keys in (delim[p-1], delim[p]]), ONE all-to-all(v) moves the
-    ranges, and each rank sorts what it received (world sorted runs).  A single key value heavier
-    than 1/world of the data cannot be split (the reference's limitation too): balance degrades,
-    the result stays correct as long as ``recv`` is large enough."""
+def sort_sharded_u32_sampled(engine, keys, recv, dist, world: int, group=None, sample_per_rank: int = 65536,
+                             seed: int = 0x5EED0007):
+    """Skew-robust variant, the reference's own scheme (src/msb_64.c:1511-1564) with one range per rank:
+
+      * every rank draws ``sample_per_rank`` keys at random from its UNSORTED shard
+        (``engine.sample_u32``: index = mulhi(rand64, n), :1511-1521) -- nothing is sorted before the exchange;
+      * the samples are all-gathered and sorted (``engine.sort_u32``, the reference sorts its sample with
+        eight passes of partition_keys, :1526-1541);
+      * world-1 equi-depth delimiters with the reference's duplicate rule (``engine.splitters_u32``,
+        extract_delimiters :1304-1322) -- identical on every rank, the sample being the same;
+      * ONE in-place pass cuts the shard into the ranges (delim[p-1], delim[p]]
+        (``engine.partition_by_splitters``, the lower-bound range function :188-204);
+      * count exchange, ONE all-to-all(v), ONE local sort of what arrived.
+
+    A single key value heavier than 1/world of the data cannot be split (the reference's limitation too):
+    balance degrades, the result stays correct as long as ``recv`` is large enough (else
+    :class:`ReceiveOverflow` on every rank)."""
     import torch
     if world == 1:
         engine.sort_u32(keys)
         return keys
     n = keys.numel()
-    engine.sort_u32(keys)
-    # ---- sample: equidistant picks of the sorted shard (as unsigned values in int64)
     m = min(sample_per_rank, n)
-    idx = (torch.arange(m, device=keys.device, dtype=torch.int64) * n) // max(m, 1)
-    mine = keys[idx].to(torch.int64) & 0xFFFFFFFF
+    mine = engine.sample_u32(keys, m, seed + 7919 * _rank(dist, group))
+    # ranks may hold different numbers of keys: gather the sample sizes, then the (padded) samples
     cnt = torch.tensor([m], dtype=torch.int64, device=keys.device)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
-    mmax = int(max(int(c.item()) for c in cnts))
-    pad = torch.full((mmax,), -1, dtype=torch.int64, device=keys.device)
+    sizes = [int(c.item()) for c in cnts]
+    mmax = max(sizes)
+    pad = torch.zeros(max(mmax, 1), dtype=torch.int32, device=keys.device)
     pad[:m] = mine
     allp = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(allp, pad, group=group)
-    sample = torch.cat([p[: int(c.item())] for p, c in zip(allp, cnts)]).sort().values.cpu().numpy()
-    delim = splitters_equi_depth(sample, world) if len(sample) else [0] * (world - 1)
-    # ---- cut the sorted shard: keys <= delim[p] belong to ranges <= p
-    ukeys = keys.to(torch.int64) & 0xFFFFFFFF
-    d = torch.tensor(delim, dtype=torch.int64, device=keys.device)
-    cuts = torch.searchsorted(ukeys, d, right=True)
-    bounds = torch.cat([torch.zeros(1, dtype=torch.int64, device=keys.device), cuts,
-                        torch.tensor([n], dtype=torch.int64, device=keys.device)])
-    send = bounds[1:] - bounds[:-1]
-    got = torch.empty_like(send)
-    dist.all_to_all_single(got, send, group=group)
-    send_l, got_l = send.tolist(), got.tolist()
-    total = int(sum(got_l))
-    if total > recv.numel():
-        raise RuntimeError(f"receive buffer too small: {total} keys for capacity {recv.numel()}")
-    out = recv[:total]
+    sample = torch.cat([p[:s] for p, s in zip(allp, sizes)]).contiguous()
+    if sample.numel():
+        engine.sort_u32(sample)
+        delim = engine.splitters_u32(sample, world)                      # int32[world-1], on the device
+    else:
+        delim = torch.zeros(world - 1, dtype=torch.int32, device=keys.device)
+    send = engine.partition_by_splitters(keys, delim, world)            # int64[world]: range sizes, ranges contiguous
+    send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
+    out = recv[:int(sum(got_l))]
     dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
     engine.sort_u32(out)
     return out
@@ -163,7 +181,8 @@ def splitters_equi_depth(sorted_sample, parts: int):
     """parts-1 equi-depth delimiters from a sorted sample with the reference's duplicate
     rule (extract_delimiters, src/msb_64.c:1304-1322): if more repetitions of the picked
     value lie after the pick than before it, use value-1 so a heavy value does not
-    straddle two ranges.  Range p = keys in (delim[p-1], delim[p]]."""
+    straddle two ranges.  Range p = keys in (delim[p-1], delim[p]].  Host restatement (numpy / lists) of
+    what ``msd_splitters_u32`` computes on the device; the tests check both against the compiled reference."""
     n = len(sorted_sample)
     out = []
     pct = n * 1.0 / parts

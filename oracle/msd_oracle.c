@@ -496,3 +496,58 @@ void orc_gen_zipf_u32(uint32_t *out, uint64_t n, uint64_t seed, uint64_t first)
 		out[i] = (uint32_t)((uint64_t)r - 1);
 	}
 }
+
+/* ------------------------------------------------ splitter front end (skew) */
+
+/* high 64 bits of a 64 x 64 bit product (src/msb_64.c:178-186: mulq) */
+static inline uint64_t orc_mulhi(uint64_t a, uint64_t b)
+{
+	return (uint64_t)(((unsigned __int128)a * b) >> 64);
+}
+
+/* random sample of an unsorted array: sample[p] = keys[mulhi(rand64, size)] (src/msb_64.c:1511-1521).
+ * The reference draws rand64 from its MT19937-64 with an uninitialised seed;
+ * the build's counter-based generator stands in: rand64 = splitmix64(seed + p). */
+void orc_sample_u32(const uint32_t *keys, uint64_t n, uint64_t m, uint64_t seed, uint32_t *out)
+{
+	for (uint64_t p = 0; p < m; ++p) out[p] = keys[orc_mulhi(orc_splitmix64(seed + p), n)];
+}
+
+/* extract_delimiters (src/msb_64.c:1304-1322) for `parts` ranges (parts - 1 delimiters):
+ * delimiter i = sample[(uint64)(percentile * (i+1) - 0.001)], percentile = sample_size / parts; if the run
+ * of equal values around the pick extends further behind it than in front of it (and the value is
+ * not 0) the delimiter is value - 1. */
+void orc_extract_delimiters(const uint64_t *sample, uint64_t sample_size, uint64_t parts, uint64_t *delimiter)
+{
+	double percentile = sample_size * 1.0 / parts;
+	for (uint64_t i = 0; i + 1 < parts; ++i) {
+		uint64_t index = (uint64_t)(percentile * (i + 1) - 0.001);
+		uint64_t start, end;
+		delimiter[i] = sample[index];
+		for (start = index; start; --start)
+			if (sample[start] != delimiter[i]) break;
+		for (end = index; end != sample_size; ++end)
+			if (sample[end] != delimiter[i]) break;
+		if (index - start < end - index && delimiter[i]) delimiter[i]--;
+	}
+}
+
+/* lower-bound range function (binary_search_64, src/msb_64.c:188-204): number of delimiters < key,
+ * i.e. range p holds the keys in (delimiter[p-1], delimiter[p]] */
+uint64_t orc_range_of(const uint64_t *delimiter, uint64_t ndelim, uint64_t key)
+{
+	uint64_t low = 0, high = ndelim;
+	while (low < high) {
+		uint64_t mid = (low + high) >> 1;
+		if (key > delimiter[mid]) low = mid + 1;
+		else high = mid;
+	}
+	return low;
+}
+
+/* range sizes of a u32 array under `ndelim` delimiters (counts[0 .. ndelim]) */
+void orc_range_histogram_u32(const uint32_t *keys, uint64_t n, const uint64_t *delimiter, uint64_t ndelim, uint64_t *counts)
+{
+	for (uint64_t p = 0; p <= ndelim; ++p) counts[p] = 0;
+	for (uint64_t i = 0; i < n; ++i) counts[orc_range_of(delimiter, ndelim, keys[i])]++;
+}

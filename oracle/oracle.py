@@ -77,6 +77,11 @@ class _Orc:
         L.orc_check.argtypes = [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int, _u64p, _u64p]
         for g, ty in (("orc_gen_uniform_u32", _u32p), ("orc_gen_uniform_u64", _u64p), ("orc_gen_zipf_u32", _u32p)):
             getattr(L, g).argtypes = [ty, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_sample_u32.argtypes = [_u32p, C.c_uint64, C.c_uint64, C.c_uint64, _u32p]
+        L.orc_extract_delimiters.argtypes = [_u64p, C.c_uint64, C.c_uint64, _u64p]
+        L.orc_range_of.restype = C.c_uint64
+        L.orc_range_of.argtypes = [_u64p, C.c_uint64, C.c_uint64]
+        L.orc_range_histogram_u32.argtypes = [_u32p, C.c_uint64, _u64p, C.c_uint64, _u64p]
 
 
 _orc = None
@@ -184,6 +189,50 @@ def gen_zipf_u32(n: int, seed: int = 0x5EED0003, first: int = 0) -> np.ndarray:
     out = np.empty(n, np.uint32)
     orc().lib.orc_gen_zipf_u32(_ptr(out, _u32p), n, seed, first)
     return out
+
+
+# ------------------------------------------------ splitter front end (skew)
+
+def sample_u32(keys: np.ndarray, m: int, seed: int = 0x5EED0007) -> np.ndarray:
+    """sample[p] = keys[mulhi(splitmix64(seed + p), n)] (sampling of src/msb_64.c:1511-1521)."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    out = np.empty(m, np.uint32)
+    orc().lib.orc_sample_u32(_ptr(keys, _u32p), keys.size, m, seed, _ptr(out, _u32p))
+    return out
+
+
+def extract_delimiters(sorted_sample: np.ndarray, parts: int) -> np.ndarray:
+    """parts-1 delimiters of a sorted sample (extract_delimiters, src/msb_64.c:1304-1322)."""
+    s = np.ascontiguousarray(sorted_sample, np.uint64)
+    out = np.zeros(max(parts - 1, 0), np.uint64)
+    if parts > 1:
+        orc().lib.orc_extract_delimiters(_ptr(s, _u64p), s.size, parts, _ptr(out, _u64p))
+    return out
+
+
+def range_histogram_u32(keys: np.ndarray, delimiters: np.ndarray) -> np.ndarray:
+    """Range sizes under the lower-bound range function (binary_search_64, src/msb_64.c:188-204)."""
+    keys = np.ascontiguousarray(keys, np.uint32)
+    d = np.ascontiguousarray(delimiters, np.uint64)
+    out = np.zeros(d.size + 1, np.uint64)
+    orc().lib.orc_range_histogram_u32(_ptr(keys, _u32p), keys.size, _ptr(d, _u64p), d.size, _ptr(out, _u64p))
+    return out
+
+
+def range_of_u32(keys: np.ndarray, delimiters: np.ndarray) -> np.ndarray:
+    """Range id per key (numpy form of the same lower bound: number of delimiters < key)."""
+    return np.searchsorted(np.asarray(delimiters, np.uint64), np.asarray(keys, np.uint64), side="left")
+
+
+def ref_extract_delimiters(sorted_sample: np.ndarray, parts: int) -> np.ndarray:
+    """The reference's own extract_delimiters (oracle/_ref), which finds `parts` from a ~0 terminator (:1307)."""
+    s = np.ascontiguousarray(sorted_sample, np.uint64)
+    delim = np.zeros(parts, np.uint64)
+    delim[parts - 1] = np.uint64(2**64 - 1)
+    L = ref().lib
+    L.extract_delimiters.argtypes = [_u64p, C.c_uint64, _u64p]
+    L.extract_delimiters(_ptr(s, _u64p), s.size, _ptr(delim, _u64p))
+    return delim[:parts - 1].copy()
 
 
 # ------------------------------------------------------------ real reference

@@ -363,6 +363,32 @@ def test_full_size_properties(ctx, logn, kind):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("shr,name", [(0, "5a: full 64-bit keys"), (32, "5b: upper 32 key bits zero")])
+def test_pairs_at_baseline_size(ctx, shr, name):
+    """BASELINE.json configs[4] at its stated size, 2^30 (u64 key, u64 rid) tuples = 32 GiB: sorted, key == rid (the
+    reference's own check(..., same=1) convention, src/msb_64.c:2461), key sum and xor preserved.  At this size the
+    second round of 5a places its blocks directly at default thresholds (parents of 2^22 tuples)."""
+    import torch
+    n = 1 << 30
+    k = torch.empty(n, dtype=torch.int64, device="cuda")
+    ctx.gen_uniform_u64(k, shift_right=shr)
+    r = k.clone()
+    v0, s0, x0 = ctx.check(k)
+    assert v0 > 0
+    ctx.sort_pairs_u64(k, r)
+    st = ctx.stats()
+    v, s, x = ctx.check(k, r)  # order + key == rid
+    assert (v, s, x) == (0, s0, x0)
+    assert st.get("direct_rounds", 0) >= 2, st
+    if shr:
+        assert st.get("skipped_bits", 0) == 32, st
+    m = 1 << 20   # spot-check against the oracle's order on the smallest 2^20 tuples
+    h = host(k[:m])
+    assert (np.diff(h.astype(np.float64)) >= 0).all() and (h == host(r[:m])).all()
+    del k, r
+    torch.cuda.empty_cache()
+
+
 def test_pairs_full_size_properties(ctx):
     """BASELINE.json configs[4] shape at 2^26 tuples (5a full 64-bit keys, 5b upper half zero)."""
     import torch

@@ -146,3 +146,26 @@ def test_histogram_and_partition_equal_reference():
         a = O.partition(k, r, shift, rb, buf)
         b = O.ref_partition(k, r, shift, rb, buf)
         assert all((x == y).all() for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("kind,parts", [("zipf", 2), ("zipf", 8), ("zipf", 64), ("uniform", 8), ("dup", 8), ("const", 4)])
+def test_splitter_front_end_equals_reference(kind, parts):
+    """extract_delimiters (src/msb_64.c:1304-1322) restated in the oracle == the reference's own, on sorted samples
+    drawn the way the build draws them (mulhi(rand64, n) indices, :1511-1521); the range function (:188-204) agrees
+    with numpy's lower bound."""
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    n, m = 200000, 5000
+    if kind == "zipf":
+        k = O.gen_zipf_u32(n, seed=11)
+    elif kind == "uniform":
+        k = O.gen_uniform_u32(n, seed=12)
+    elif kind == "dup":
+        k = (O.gen_uniform_u32(n, seed=13) % 5).astype(np.uint32) * 1000
+    else:
+        k = np.full(n, 77, np.uint32)
+    s = np.sort(O.sample_u32(k, m, seed=99)).astype(np.uint64)
+    d = O.extract_delimiters(s, parts)
+    assert (d == O.ref_extract_delimiters(s, parts)).all()
+    cnt = O.range_histogram_u32(k, d)
+    assert int(cnt.sum()) == n and (cnt == np.bincount(O.range_of_u32(k, d), minlength=parts)).all()
