@@ -7,11 +7,14 @@
 """
 import collections, csv, glob, json, os, shutil, sys
 tag, rnd = sys.argv[1], sys.argv[2]
+cfg = sys.argv[3] if len(sys.argv) > 3 else "c2"          # bench.py --config the profile was taken with
+sfx = "" if cfg == "c2" else f"_{cfg}"
+SORTS_IN_PMC_RUN = 2   # tools/profile_bench.sh: bench.py --steps 1 --warmup 0 = one timed sort + the profiled one
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 st = max(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # newest run
-shutil.copy(st, f"profiles/{rnd}_kernel_stats.csv")
-shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench.json")
+shutil.copy(st, f"profiles/{rnd}_kernel_stats{sfx}.csv")
+shutil.copy(os.path.join(src, "bench.json"), f"profiles/{rnd}_bench{sfx}.json")
 
 def short(name):
     n = name.replace("void msd::", "").replace("msd::", "")
@@ -39,14 +42,20 @@ for k in sorted(set(acc["fetch"]) | set(acc["write"])):
     rows.append((k, launches, fv, wv, fetch_b, write_b))
     js[k] = {"launches_profiled": launches, "hbm_read_bytes_per_launch": int(fetch_b), "hbm_write_bytes_per_launch": int(write_b),
              "hbm_bytes_per_launch": int(fetch_b + write_b)}
-with open(f"profiles/{rnd}_pmc_traffic.csv", "w") as o:
+# bytes one whole sort moves: every kernel of the library (not the generators, checks and copies of the harness)
+harness = ("gen_", "check_kernel", "__amd_rocclr", "at::", "vectorized", "elementwise")
+per_sort = sum((r[4] + r[5]) * r[1] for r in rows if not any(h in r[0] for h in harness)) / SORTS_IN_PMC_RUN
+js["__per_sort__"] = {"hbm_bytes": int(per_sort), "sorts_in_profiled_run": SORTS_IN_PMC_RUN,
+                      "note": "sum over the library's kernels of corrected FETCH_SIZE + WRITE_SIZE, per sort"}
+with open(f"profiles/{rnd}_pmc_traffic{sfx}.csv", "w") as o:
     o.write("kernel,launches,FETCH_SIZE_sum_KiB_raw,WRITE_SIZE_sum_KiB,read_bytes_per_launch_corrected_x2,write_bytes_per_launch\n")
     for r in rows:
         o.write(",".join(str(x) for x in r) + "\n")
-json.dump(js, open("profiles/pmc_traffic.json", "w"), indent=1)
+json.dump(js, open(f"profiles/pmc_traffic{sfx}.json", "w"), indent=1)
 for row in csv.DictReader(open(st)):
     if float(row["Percentage"]) > 0.5:
         print(f"{short(row['Name'])[:46]:46s} calls={row['Calls']:>4} avg_us={float(row['AverageNs'])/1e3:10.1f} pct={row['Percentage']}")
+print(f"per sort: {per_sort/1e9:.2f} GB")
 for k, v in js.items():
-    if v["hbm_bytes_per_launch"] > 1e8:
+    if k != "__per_sort__" and v["hbm_bytes_per_launch"] > 1e8:
         print(f"{k[:46]:46s} HBM read {v['hbm_read_bytes_per_launch']/1e9:7.2f} GB  write {v['hbm_write_bytes_per_launch']/1e9:7.2f} GB per launch")
