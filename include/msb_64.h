@@ -18,12 +18,19 @@
  *     reference asserts, src/msb_64.c:2266, 2273-2276).
  * Re-interpreted (documented in INTEGRATION.md):
  *   - threads is accepted and ignored (the reference demands 64); numa is the
- *     number of caller arrays; fudge only has to be >= 1.0 because the GPU
- *     path needs no slack inside the caller's arrays; size[] is left as it was
- *     (the reference redistributes it by sampled splitters, :2180, which is
- *     implementation-defined).
- *   - the phases reported are the GPU pipeline's (H2D, digit passes, local
- *     sort, D2H), not the CPU block machinery's.
+ *     number of caller arrays (all of them are sorted on device 0: one GPU
+ *     holds 2^33 tuples); fudge only has to be >= 1.0.
+ *   - size[] IS rewritten, as the reference does (src/msb_64.c:2180, sum preserved :2379-2383): the
+ *     reference gives every node whole key ranges; here array a keeps the cut at the end of its
+ *     input share unless a run of equal keys straddles it -- then the cut moves to the nearer end
+ *     of that run, provided the growing array stays within its capacity size[a] * fudge (what the
+ *     reference requires the caller to allocate, :1574-1578).  So with fudge > 1 no key value is
+ *     split between two arrays; with fudge = 1.0 size[] comes back unchanged.
+ *   - the phases reported are the GPU pipeline's: times[0] host-to-device staging (pinned,
+ *     chunked, several copy streams), [1..7] the device phases (every device phase has a slot:
+ *     they add up to the device time), [8] device-to-host staging, [9] the whole call.
+ *   - arrays that do not fit the device memory: nothing is sorted, a message goes to stderr,
+ *     times[] come back zero and msb_64_last_error() says why (void API, no abort).
  */
 #ifndef MSB_64_H_HIP_
 #define MSB_64_H_HIP_
@@ -39,6 +46,9 @@ extern "C" {
 void sort(uint64_t **keys, uint64_t **rids, uint64_t *size,
 	  int threads, int numa, double fudge,
 	  char **description, uint64_t *times);
+
+/* empty string after a successful sort(), else why the last one did nothing (no counterpart in the reference) */
+const char *msb_64_last_error(void);
 
 /* reference: include/msb_64.h:41, src/msb_64.c:111-115 (64-byte aligned, free()) */
 void *mamalloc(size_t size);

@@ -19,7 +19,7 @@ SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
 DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_count16.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
                   os.path.join("..", "..", "include", "msb_64.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-pthread"]
 
 
 def _hipcc() -> str:

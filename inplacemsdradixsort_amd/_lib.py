@@ -24,7 +24,7 @@ EXPORTS = [
     "msd_gen_uniform_u32", "msd_gen_uniform_u64", "msd_gen_zipf_u32", "msd_gen_iota_u64",
     "msd_plan_first_round",
     "msd_set_option", "msd_set_profiling", "msd_phase_count", "msd_phase_name", "msd_phase_us", "msd_stat",
-    "sort", "mamalloc", "check",
+    "sort", "mamalloc", "check", "msb_64_last_error",
 ]
 
 _lib = None

@@ -338,6 +338,37 @@ def test_reference_api_sort_and_check(ctx):
     assert int(times[9]) >= int(times[0])
 
 
+def test_reference_api_rewrites_size_at_key_boundaries():
+    """sort() rewrites size[] like the reference (src/msb_64.c:2180; the sum is preserved, :2379-2383): with fudge > 1 a run
+    of equal keys that straddles two arrays moves whole into one of them (the reference hands every node whole key
+    ranges); times[0..8] add up to times[9]; fudge = 1.0 leaves size[] alone."""
+    import inplacemsdradixsort_amd as M
+    n0, n1, n2 = 100000, 60000, 30001
+    k = (O.gen_uniform_u64(n0 + n1 + n2, seed=33) % np.uint64(50)) * np.uint64(0x0101010101)   # 50 values, runs of ~3800
+    for fudge in (2.0, 1.0):
+        caps = [int(x * fudge) for x in (n0, n1, n2)]
+        keys = [M.mamalloc(c * 8).view(np.uint64) for c in caps]
+        rids = [M.mamalloc(c * 8).view(np.uint64) for c in caps]
+        parts = [k[:n0], k[n0:n0 + n1], k[n0 + n1:]]
+        for a in range(3):
+            keys[a][:parts[a].size] = parts[a]
+            rids[a][:parts[a].size] = parts[a]
+        size = [n0, n1, n2]
+        desc, times = M.sort(keys, rids, size, threads=64, numa=3, fudge=fudge)
+        assert sum(size) == n0 + n1 + n2 and all(size[a] <= caps[a] for a in range(3))
+        cat = np.concatenate([keys[a][:size[a]] for a in range(3)])
+        assert (cat == np.sort(k)).all() and (np.concatenate([rids[a][:size[a]] for a in range(3)]) == cat).all()
+        if fudge > 1.0:
+            assert size != [n0, n1, n2]
+            for a in range(2):   # no key value is split between two arrays
+                assert keys[a][size[a] - 1] < keys[a + 1][0]
+        else:
+            assert size == [n0, n1, n2]
+        assert M.check(keys, rids, size, numa=3, same=True) == int(k.sum(dtype=np.uint64))
+        tm = [int(x) for x in times]
+        assert 0.6 * tm[9] <= sum(tm[:9]) <= 1.05 * tm[9] + 2000, tm
+
+
 @pytest.mark.parametrize("logn,kind", [(26, "uniform"), (26, "zipf"), (30, "uniform"), (30, "zipf"), (32, "uniform")])
 def test_full_size_properties(ctx, logn, kind):
     """BASELINE.json configs[1], [2] at full size: sorted, checksums preserved, idempotent."""
