@@ -124,6 +124,13 @@ int msd_gen_uniform_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t see
 int msd_gen_uniform_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, uint64_t seed, uint64_t first, int shift_right);
 int msd_gen_zipf_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t seed, uint64_t first);
 int msd_gen_iota_u64(msd_ctx *ctx, uint64_t *d_vals, uint64_t n, uint64_t first);
+/* duplicates: `distinct` different values with evenly spread digits, each about n / distinct times:
+ * key[i] = splitmix64((splitmix64(seed + first + i) mod distinct) ^ 0xD0B1E5) >> 32 */
+int msd_gen_dup_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t seed, uint64_t first, uint64_t distinct);
+/* the reference's own generator, MT19937-64 (src/rand.c:47-86): d_keys[i] = the i-th rand64_next() after
+ * rand64_init(seed), shifted right by shift_right -- for cross-checks against a caller that fills its arrays
+ * with the reference's RNG.  One workgroup walks the stream (a few GB/s); not a bulk generator. */
+int msd_gen_mt19937_64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, uint64_t seed, int shift_right);
 
 /* ---- pass planner (reference: schedule_passes(), src/msb_64.c:1334-1400) -------------
  * Host-only (no device needed).  The reference plans 1-3 leading passes of <= 9 bits

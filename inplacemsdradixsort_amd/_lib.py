@@ -22,6 +22,7 @@ EXPORTS = [
     "msd_sample_u32", "msd_splitters_u32", "msd_partition_by_splitters_u32",
     "msd_check_u32", "msd_check_u64",
     "msd_gen_uniform_u32", "msd_gen_uniform_u64", "msd_gen_zipf_u32", "msd_gen_iota_u64",
+    "msd_gen_dup_u32", "msd_gen_mt19937_64",
     "msd_plan_first_round",
     "msd_set_option", "msd_set_profiling", "msd_phase_count", "msd_phase_name", "msd_phase_us", "msd_stat",
     "sort", "mamalloc", "check", "msb_64_last_error",
@@ -84,6 +85,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.msd_gen_uniform_u64.argtypes = [_vp, _vp, _u64, _u64, _u64, C.c_int]
     L.msd_gen_zipf_u32.argtypes = [_vp, _vp, _u64, _u64, _u64]
     L.msd_gen_iota_u64.argtypes = [_vp, _vp, _u64, _u64]
+    L.msd_gen_dup_u32.argtypes = [_vp, _vp, _u64, _u64, _u64, _u64]
+    L.msd_gen_mt19937_64.argtypes = [_vp, _vp, _u64, _u64, C.c_int]
     L.msd_plan_first_round.argtypes = [_u64, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MsdPlan)]
     L.msd_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
     L.msd_set_profiling.argtypes = [_vp, C.c_int]

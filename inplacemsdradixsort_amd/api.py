@@ -159,6 +159,13 @@ class MsdContext:
     def gen_zipf_u32(self, keys, seed: int = 0x5EED0003, first: int = 0) -> None:
         self._ok(self._L.msd_gen_zipf_u32(self._h, self._ptr(keys, 4), keys.numel(), seed, first))
 
+    def gen_dup_u32(self, keys, distinct: int, seed: int = 0x5EED0009, first: int = 0) -> None:
+        self._ok(self._L.msd_gen_dup_u32(self._h, self._ptr(keys, 4), keys.numel(), seed, first, distinct))
+
+    def gen_mt19937_64(self, keys, seed: int, shift_right: int = 0) -> None:
+        """The reference's own RNG stream (src/rand.c:47-86) into an int64 tensor."""
+        self._ok(self._L.msd_gen_mt19937_64(self._h, self._ptr(keys, 8), keys.numel(), seed, shift_right))
+
     def gen_iota_u64(self, vals, first: int = 0) -> None:
         self._ok(self._L.msd_gen_iota_u64(self._h, self._ptr(vals, 8), vals.numel(), first))
 

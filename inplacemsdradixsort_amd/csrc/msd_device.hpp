@@ -2920,6 +2920,55 @@ __global__ void gen_iota_u64_kernel(uint64_t *out, uint64_t n, uint64_t first)
 		out[i] = first + i;
 }
 
+// `distinct` different key values, each about n / distinct times: value j = the top half of splitmix64(j ^ salt),
+// j = splitmix64(seed + i) mod distinct -- duplicates whose digits are still evenly spread (the reference's
+// comb/insertion sorts degrade on duplicates; the counting leaves here must not)
+__global__ void gen_dup_u32_kernel(uint32_t *out, uint64_t n, uint64_t seed, uint64_t distinct)
+{
+	const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+		out[i] = (uint32_t)(splitmix64((splitmix64(seed + i) % distinct) ^ 0xD0B1E5ull) >> 32);
+}
+
+// The reference's own generator, MT19937-64 (src/rand.c:47-86: rand64_init / rand64_next), as a stream on the
+// device: out[i] = the i-th rand64_next() after rand64_init(seed), shifted right by shr.  The twist of a block of
+// 312 words has two parallel halves (:65-78): words [0, 156) need only old words, words [156, 312) the new
+// words [0, 156) and (word 311) the new word 0.  One workgroup walks the stream (the recurrence is sequential
+// from block to block); it is a cross-checking aid, not a bulk generator.
+__global__ __launch_bounds__(320) void gen_mt19937_64_kernel(uint64_t *out, uint64_t n, uint64_t seed, int shr)
+{
+	__shared__ uint64_t st[313];
+	const uint32_t t = threadIdx.x;
+	if (t == 0) { // rand64_init, src/rand.c:47-58
+		st[0] = seed;
+		for (uint32_t i = 0; i != 311; ++i) st[i + 1] = 6364136223846793005ull * (st[i] ^ (st[i] >> 62)) + i + 1;
+	}
+	__syncthreads();
+	auto twist = [](uint64_t a, uint64_t b, uint64_t far) -> uint64_t {
+		const uint64_t x = (a & 0xffffffff80000000ull) | (b & 0x7fffffffull);
+		return far ^ (x >> 1) ^ (0xb5026f5aa96619e9ull & (0ull - (x & 1ull)));
+	};
+	for (uint64_t base = 0; base < n; base += 312) {
+		uint64_t v = 0;
+		if (t < 156) v = twist(st[t], st[t + 1], st[t + 156]);
+		__syncthreads();
+		if (t < 156) st[t] = v;
+		__syncthreads();
+		if (t >= 156 && t < 312) v = twist(st[t], t == 311 ? st[0] : st[t + 1], st[t - 156]);
+		__syncthreads();
+		if (t >= 156 && t < 312) st[t] = v;
+		__syncthreads();
+		if (t < 312 && base + t < n) { // tempering, src/rand.c:80-85
+			uint64_t x = st[t];
+			x ^= (x >> 29) & 0x5555555555555555ull;
+			x ^= (x << 17) & 0x71d67fffeda60000ull;
+			x ^= (x << 37) & 0xfff7eee000000000ull;
+			x ^= (x >> 43);
+			out[base + t] = x >> shr;
+		}
+	}
+}
+
 // ------------------------------------------------------- splitter service
 
 // Random sample of an (unsorted) array: out[i] = keys[mulhi(rand64, n)], as the reference draws its sample

@@ -1151,6 +1151,25 @@ int msd_gen_zipf_u32(msd_ctx *c, uint32_t *k, uint64_t n, uint64_t seed, uint64_
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }
+int msd_gen_dup_u32(msd_ctx *c, uint32_t *k, uint64_t n, uint64_t seed, uint64_t first, uint64_t distinct)
+{
+	if (!c) return MSD_EINVAL;
+	if (distinct == 0) return fail(c, MSD_EINVAL, "gen_dup: distinct must be positive");
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL(gen_dup_u32_kernel, dim3(gen_grid(c, n)), dim3(256), 0, c->stream, k, n, seed + first, distinct);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+int msd_gen_mt19937_64(msd_ctx *c, uint64_t *k, uint64_t n, uint64_t seed, int shr)
+{
+	if (!c) return MSD_EINVAL;
+	if (shr < 0 || shr > 63) return fail(c, MSD_EINVAL, "gen_mt19937_64: shift_right must be 0..63");
+	HIPCHK(c, hipSetDevice(c->device));
+	if (n == 0) return MSD_OK;
+	hipLaunchKernelGGL(gen_mt19937_64_kernel, dim3(1), dim3(320), 0, c->stream, k, n, seed, shr);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
 int msd_gen_iota_u64(msd_ctx *c, uint64_t *v, uint64_t n, uint64_t first)
 {
 	if (!c) return MSD_EINVAL;

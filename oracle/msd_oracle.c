@@ -551,3 +551,40 @@ void orc_range_histogram_u32(const uint32_t *keys, uint64_t n, const uint64_t *d
 	for (uint64_t p = 0; p <= ndelim; ++p) counts[p] = 0;
 	for (uint64_t i = 0; i < n; ++i) counts[orc_range_of(delimiter, ndelim, keys[i])]++;
 }
+
+/* duplicates generator of include/msd_radix_hip.h (msd_gen_dup_u32) */
+void orc_gen_dup_u32(uint32_t *out, uint64_t n, uint64_t seed, uint64_t first, uint64_t distinct)
+{
+	for (uint64_t i = 0; i < n; ++i)
+		out[i] = (uint32_t)(orc_splitmix64((orc_splitmix64(seed + first + i) % distinct) ^ 0xD0B1E5ull) >> 32);
+}
+
+/* MT19937-64 as the reference implements it (src/rand.c:47-86): rand64_init(seed), then n x rand64_next() */
+void orc_mt19937_64(uint64_t *out, uint64_t n, uint64_t seed)
+{
+	uint64_t num[313], x;
+	size_t index = 312, i;
+	num[0] = seed;
+	for (i = 0; i != 311; ++i) num[i + 1] = 6364136223846793005ull * (num[i] ^ (num[i] >> 62)) + i + 1;
+	for (uint64_t k = 0; k < n; ++k) {
+		if (index == 312) {
+			i = 0;
+			do {
+				x = (num[i] & 0xffffffff80000000ull) | (num[i + 1] & 0x7fffffffull);
+				num[i] = num[i + 156] ^ (x >> 1) ^ (0xb5026f5aa96619e9ull & (0ull - (x & 1)));
+			} while (++i != 156);
+			num[312] = num[0];
+			do {
+				x = (num[i] & 0xffffffff80000000ull) | (num[i + 1] & 0x7fffffffull);
+				num[i] = num[i - 156] ^ (x >> 1) ^ (0xb5026f5aa96619e9ull & (0ull - (x & 1)));
+			} while (++i != 312);
+			index = 0;
+		}
+		x = num[index++];
+		x ^= (x >> 29) & 0x5555555555555555ull;
+		x ^= (x << 17) & 0x71d67fffeda60000ull;
+		x ^= (x << 37) & 0xfff7eee000000000ull;
+		x ^= (x >> 43);
+		out[k] = x;
+	}
+}

@@ -77,6 +77,8 @@ class _Orc:
         L.orc_check.argtypes = [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int, _u64p, _u64p]
         for g, ty in (("orc_gen_uniform_u32", _u32p), ("orc_gen_uniform_u64", _u64p), ("orc_gen_zipf_u32", _u32p)):
             getattr(L, g).argtypes = [ty, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_gen_dup_u32.argtypes = [_u32p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_mt19937_64.argtypes = [_u64p, C.c_uint64, C.c_uint64]
         L.orc_sample_u32.argtypes = [_u32p, C.c_uint64, C.c_uint64, C.c_uint64, _u32p]
         L.orc_extract_delimiters.argtypes = [_u64p, C.c_uint64, C.c_uint64, _u64p]
         L.orc_range_of.restype = C.c_uint64
@@ -189,6 +191,30 @@ def gen_zipf_u32(n: int, seed: int = 0x5EED0003, first: int = 0) -> np.ndarray:
     out = np.empty(n, np.uint32)
     orc().lib.orc_gen_zipf_u32(_ptr(out, _u32p), n, seed, first)
     return out
+
+
+def gen_dup_u32(n: int, distinct: int, seed: int = 0x5EED0009, first: int = 0) -> np.ndarray:
+    out = np.empty(n, np.uint32)
+    orc().lib.orc_gen_dup_u32(_ptr(out, _u32p), n, seed, first, distinct)
+    return out
+
+
+def mt19937_64(n: int, seed: int) -> np.ndarray:
+    """rand64_init(seed) + n x rand64_next() as the reference implements them (src/rand.c:47-86)."""
+    out = np.empty(n, np.uint64)
+    orc().lib.orc_mt19937_64(_ptr(out, _u64p), n, seed)
+    return out
+
+
+def ref_mt19937_64(n: int, seed: int) -> np.ndarray:
+    """The same stream from the reference's own rand.c (oracle/_ref)."""
+    L = ref().lib
+    L.rand64_init.restype = C.c_void_p
+    L.rand64_init.argtypes = [C.c_uint64]
+    L.rand64_next.restype = C.c_uint64
+    L.rand64_next.argtypes = [C.c_void_p]
+    st = L.rand64_init(seed)
+    return np.array([L.rand64_next(st) for _ in range(n)], dtype=np.uint64)
 
 
 # ------------------------------------------------ splitter front end (skew)

@@ -319,6 +319,24 @@ def test_device_generators_match_oracle(ctx):
     assert (np.abs(z - ez) <= np.maximum(1, ez >> 40)).all() and (z != ez).mean() < 1e-3
 
 
+def test_duplicates_and_mt19937_generators_match_oracle(ctx):
+    """msd_gen_dup_u32 and the MT19937-64 stream (the reference's own RNG, src/rand.c:47-86) are bit-identical to the
+    oracle's restatements (the MT one is pinned to the reference's rand.c in tests/test_oracle.py); duplicate-heavy keys sort."""
+    import torch
+    n = 200001
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    for distinct in (1, 7, 1000, 1 << 20):
+        ctx.gen_dup_u32(t, distinct, seed=77, first=5)
+        want = O.gen_dup_u32(n, distinct, seed=77, first=5)
+        assert (host(t) == want).all()
+        ctx.sort_u32(t)
+        assert (host(t) == np.sort(want)).all()
+    m = torch.empty(5000, dtype=torch.int64, device="cuda")
+    for seed, shr in ((5489, 0), (0x5EED0001, 32)):
+        ctx.gen_mt19937_64(m, seed, shift_right=shr)
+        assert (host(m) == (O.mt19937_64(5000, seed) >> np.uint64(shr))).all()
+
+
 def test_reference_api_sort_and_check(ctx):
     """sort()/check()/mamalloc of include/msb_64.h on host arrays, two caller arrays ('numa' = 2)."""
     import inplacemsdradixsort_amd as M

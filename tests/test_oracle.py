@@ -169,3 +169,13 @@ def test_splitter_front_end_equals_reference(kind, parts):
     assert (d == O.ref_extract_delimiters(s, parts)).all()
     cnt = O.range_histogram_u32(k, d)
     assert int(cnt.sum()) == n and (cnt == np.bincount(O.range_of_u32(k, d), minlength=parts)).all()
+
+
+def test_mt19937_64_restatement_equals_reference_rand_c():
+    """src/rand.c:47-86 restated in the oracle == the reference's rand64_init / rand64_next (across a block boundary)."""
+    if not O.have_ref():
+        pytest.skip("needs oracle/_ref")
+    for seed in (0, 1, 0x5EED0001, 2**64 - 1):
+        assert (O.mt19937_64(1000, seed) == O.ref_mt19937_64(1000, seed)).all()
+    # known-answer: std::mt19937_64's 10000th output for the default seed 5489 (the C++ standard pins it)
+    assert int(O.mt19937_64(10000, 5489)[-1]) == 9981545732273789042
