@@ -184,7 +184,8 @@ class MsdContext:
     def stats(self) -> Dict[str, int]:
         out = {}
         for name in ("rounds", "parents", "stripes", "children", "slots", "holes", "chain_steps",
-                     "small_segments", "count_segments", "big_count_segments", "direct_rounds", "skipped_bits", "workspace_bytes"):
+                     "small_segments", "count_segments", "big_count_segments", "direct_rounds", "regpart_rounds", "skipped_bits",
+                     "workspace_bytes"):
             v = C.c_uint64()
             if self._L.msd_stat(self._h, name.encode(), C.byref(v)) == 0:
                 out[name] = int(v.value)

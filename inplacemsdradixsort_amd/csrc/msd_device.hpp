@@ -118,7 +118,7 @@ static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used
 // -DMSD_STAMPS (tools/stamps_build.sh, never the shipped library): wave 0 (a "bucket wave") and the last wave of
 // every classify_direct workgroup add the shader cycles they spend in each section of the tile loop to
 // g_stamps[which wave][section]; read back with msd_debug_stamps().
-#ifdef MSD_STAMPS // = 1: classify_direct kernels, 2: count_place_kernel
+#ifdef MSD_STAMPS // = 1: classify_direct kernels, 2: count_place kernels, 3: leaf_count_sort_kernel
 __device__ unsigned long long g_stamps[2][16];
 #define MSD_STAMP_DECL(id)                          \
 	constexpr bool kStampThis = MSD_STAMPS == (id); \
@@ -649,11 +649,12 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 			for (int u = 0; u < U; ++u) {
 				const uint32_t vv = min(v + (uint32_t)u * 1024u, nvec - 1u);
 				if constexpr (sizeof(K) == 4) {
-					const uint4 q = *reinterpret_cast<const uint4 *>(kp + (size_t)vv * VEC);
+					// (nontemporal: a read-once stream; tools/microbench/stream_copy.hip reads 7.0 TB/s this way, 6.3 plain)
+					const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kp + (size_t)vv * VEC));
 					kk[u][0] = q.x; kk[u][1] = q.y; kk[u][2] = q.z; kk[u][3] = q.w;
 				} else {
-					const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(kp + (size_t)vv * VEC);
-					kk[u][0] = q.x; kk[u][1] = q.y;
+					const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(kp + (size_t)vv * VEC));
+					kk[u][0] = (K)q.x | ((K)q.y << 32); kk[u][1] = (K)q.z | ((K)q.w << 32);
 				}
 			}
 #pragma unroll
@@ -1787,6 +1788,10 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 	}
 }
 
+} // namespace msd
+#include "msd_regpart.hpp"
+namespace msd {
+
 // ------------------------------------------------- one-pass counting sort
 
 // A segment whose keys differ only in their low `bits` <= 16 bits is finished in ONE
@@ -2157,7 +2162,11 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 		}
 	};
 	prefetch(sg);
+	MSD_STAMP_DECL(3);
+	MSD_STAMP_START();
 	for (;;) {
+		MSD_STAMP(9); // loop
+		MSD_STAMP_TICK(11);
 		const uint32_t n = (uint32_t)sg.count;
 		K k_or = 0, k_and = ~(K)0;
 #pragma unroll
@@ -2174,6 +2183,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 			wtot[17] = atomicAdd(ticket, 1u) + gridDim.x;
 		}
 		for (uint32_t j = tid; j < ((uint32_t)1 << LB) / 2; j += TH) cw[j] = 0;
+		MSD_STAMP(0); // wait for the keys + OR/AND + clear
 		__syncthreads();
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) {
@@ -2190,7 +2200,11 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 			}
 		}
 		__syncthreads();
+		MSD_STAMP(1); // B + merge + B
 		const uint32_t nxt = wtot[17];
+		// the next segment's descriptor travels during the counting phases (loaded where its elements are prefetched,
+		// its whole memory latency would sit in front of that prefetch)
+		const Segment nraw = segs[nxt < nsegs ? nxt : blockIdx.x];
 		const K openmask = sg.bits >= sizeof(K) * 8 ? ~(K)0 : (((K)1 << sg.bits) - 1);
 		const K vopen = (s_or[0] ^ s_or[1]) & openmask;
 		Segment nsg = sg;
@@ -2208,6 +2222,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 					rk[i] = (atomicAdd(&cw[v >> 1], 1u << sh) >> sh) & 0xFFFFu;
 				}
 			}
+			MSD_STAMP(2); // fetch-adds
 			__syncthreads();
 			// counts -> exclusive positions, in place; thread t owns 8 words
 			constexpr uint32_t WPT = (((uint32_t)1 << LB) / 2) / TH;
@@ -2231,6 +2246,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 				cw[w0 + j] = run | ((run + lo) << 16);
 				run += lo + hi;
 			}
+			MSD_STAMP(3); // B + sums + scan + B + prefix
 			__syncthreads();
 #pragma unroll
 			for (int i = 0; i < KPT; ++i) {
@@ -2241,64 +2257,97 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 					if constexpr (HV) xv[p] = vr[i];
 				}
 			}
+			MSD_STAMP(4); // B + scatter into LDS
 			// the registers are free: the next segment's elements start travelling
 			if (nxt < nsegs) {
-				nsg = segs[nxt];
+				nsg = nraw;
 				prefetch(nsg);
 				fetched = true;
 			}
+			MSD_STAMP(5); // descriptor + prefetch issue
 			__syncthreads();
 			bool bad = false;
-			if (shift) { // more bits vary than were counted: order the groups of equal counted bits by whole keys
-				const K lowmask = ((K)1 << shift) - 1;
+			const K lowmask = shift ? ((K)1 << shift) - 1 : (K)0;
+			const bool groups = shift && (vopen & lowmask) != 0; // more bits vary than were counted
+			constexpr uint32_t kMaxGroup = 48;
+			if (groups) {
+				// a group (elements equal on the counted bits; contiguous by now) longer than kMaxGroup sends the untouched
+				// segment to the general LDS sort: with the groups in order, two elements kMaxGroup apart share a group
+				// only if the group is longer than that
 				bool too_long = false;
-				if ((vopen & lowmask) != 0) {
-					for (uint32_t i = tid; i < n; i += TH) {
-						const K hi = xk[i] >> shift;
-						if ((i == 0 || (xk[i - 1] >> shift) != hi) && i + 1 < n && (xk[i + 1] >> shift) == hi) {
-							uint32_t e = i + 2;
-							while (e < n && (xk[e] >> shift) == hi) ++e;
-							if (e - i > 48) {
-								too_long = true;
-							} else {
-								for (uint32_t a = i + 1; a < e; ++a) {
-									const K ka = xk[a];
-									uint64_t va = 0;
-									if constexpr (HV) va = xv[a];
-									uint32_t b = a;
-									while (b > i && xk[b - 1] > ka) {
-										xk[b] = xk[b - 1];
-										if constexpr (HV) xv[b] = xv[b - 1];
-										--b;
-									}
-									xk[b] = ka;
-									if constexpr (HV) xv[b] = va;
-								}
-							}
-						}
-					}
-				}
+				for (uint32_t i = tid; i + kMaxGroup < n; i += TH)
+					if ((xk[i] >> shift) == (xk[i + kMaxGroup] >> shift)) too_long = true;
 				if (too_long) wtot[16] = 1;
 				__syncthreads();
 				bad = wtot[16] != 0;
-				// nothing has been written back yet: the general LDS sort takes the segment as it is
-				if (bad && tid == 0) fallback[atomicAdd(&ctr->nfallback, 1u)] = sg;
+				if (bad && tid == 0) fallback[atomicAdd(&ctr->nfallback, 1u)] = sg; // (nothing has been written back)
 			}
-			if (!bad) {
+			MSD_STAMP(6); // B + long-group check
+			if (!bad && groups) {
+				// Write-back with the groups put in order on the way: every element finds its own place inside its group --
+				// first slot of the group + the members with a smaller key (or an equal key further left) -- by scanning
+				// its few neighbours in LDS, and goes straight to that place in the array.  LDS is only read, so no element
+				// waits for another (one thread per group running an insertion sort through dependent LDS round trips was
+				// half of this kernel's time for tuples and four fifths for u64 keys, profiles/r02_stamps_leaf_before.json).
+				// (the three neighbours on either side are read at once, clamped at the segment's ends -- one LDS round trip
+				// covers nearly every group; only longer groups continue element by element)
+				constexpr uint32_t WIN = 3;
+#pragma unroll 1
+				for (uint32_t idx = tid; idx < n; idx += TH) {
+					const K me = xk[idx], hi = me >> shift;
+					K lk[WIN], rkk[WIN];
+#pragma unroll
+					for (uint32_t d = 0; d < WIN; ++d) {
+						lk[d] = xk[idx > d ? idx - d - 1 : 0u];
+						rkk[d] = xk[min(idx + d + 1, n - 1u)];
+					}
+					uint32_t left = 0, before = 0, right = 0;
+					bool ml = true, mr = true;
+#pragma unroll
+					for (uint32_t d = 0; d < WIN; ++d) {
+						ml = ml && idx > d && (lk[d] >> shift) == hi;      // members to the left: those <= me come first
+						before += ml && lk[d] <= me ? 1u : 0u;
+						left += ml ? 1u : 0u;
+						mr = mr && idx + d + 1 < n && (rkk[d] >> shift) == hi; // members to the right: those < me come first
+						before += mr && rkk[d] < me ? 1u : 0u;
+						right += mr ? 1u : 0u;
+					}
+					if (ml) { // the group goes on beyond the window
+						while (idx > left) {
+							const K o = xk[idx - left - 1];
+							if ((o >> shift) != hi) break;
+							before += o <= me ? 1u : 0u;
+							++left;
+						}
+					}
+					if (mr) {
+						for (uint32_t e = idx + right + 1; e < n; ++e) {
+							const K o = xk[e];
+							if ((o >> shift) != hi) break;
+							before += o < me ? 1u : 0u;
+						}
+					}
+					const uint64_t at = sg.start + idx - left + before;
+					keys[at] = me;
+					if constexpr (HV) vals[at] = xv[idx];
+				}
+			} else if (!bad) {
 				for (uint32_t idx = tid; idx < n; idx += TH) {
 					keys[sg.start + idx] = xk[idx];
 					if constexpr (HV) vals[sg.start + idx] = xv[idx];
 				}
 			}
 		}
+		MSD_STAMP(7); // write-back
 		if (nxt >= nsegs) break;
 		if (!fetched) {
-			nsg = segs[nxt];
+			nsg = nraw;
 			prefetch(nsg);
 		}
 		sg = nsg;
 		__syncthreads(); // LDS (exchange buffers, counters, flags) is reused
 	}
+	MSD_STAMP_FLUSH(TH / 64);
 }
 
 // ------------------------------------- counting sort for segments of any size

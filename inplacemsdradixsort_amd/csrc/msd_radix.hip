@@ -51,6 +51,7 @@ struct msd_ctx {
 	int direct_mode = 1;
 	uint64_t direct_min = 1ull << 26; // smallest round (elements) it is tried on
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
+	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
 	int direct_kernel = 2; // 1: first version of the direct classify kernel (A/B comparisons), 2: msd_direct.hpp
 };
@@ -528,6 +529,101 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	int round = 0;
 	bool prev_direct = false; // the previous round placed its blocks directly (its digit was evenly spread)
 	while (!cur.empty()) {
+		// ---- segments that fit the registers of one workgroup take ONE register-resident pass (msd_regpart.hpp) instead
+		// of a general round: the last partition round of the tuple sort (65536 parents of about 2^14 tuples at 2^30)
+		if constexpr (sizeof(K) == 8) {
+			if (!single_pass && c->regpart) {
+				std::vector<Segment> fit, rest;
+				for (auto &sg : cur) (sg.count + 1 <= kRpCap && sg.count > small_max ? fit : rest).push_back(sg);
+				if (fit.size() >= 64 || (!fit.empty() && rest.empty())) {
+					std::vector<Parent> ps(fit.size());
+					uint32_t nc = 0;
+					for (size_t i = 0; i < fit.size(); ++i) {
+						Parent &p = ps[i];
+						p.start = fit[i].start;
+						p.count = fit[i].count;
+						// the narrowest digit whose children fit the leaf sorter with a quarter to spare (the leaf's per-segment
+						// costs favour few large segments; a child that turns out too big simply takes another pass)
+						uint32_t w = 1;
+						while (w < 8 && w < fit[i].bits && (fit[i].count >> w) > small_max - small_max / 4) ++w;
+						p.width = std::min<uint32_t>(w, fit[i].bits);
+						p.shift = fit[i].bits - p.width;
+						p.child_base = nc;
+						p.stripe_lo = p.stripe_hi = 0;
+						p.pad = 0;
+						nc += 1u << p.width;
+					}
+					const uint32_t np = (uint32_t)ps.size();
+					const size_t next_cap = (size_t)nc + 2; // (children above the leaf capacity: none on sane input, all at worst)
+					Bump sz(nullptr), *bp = &sz;
+					Parent *d_parents = nullptr;
+					ChildArrays ca = {};
+					Segment *d_next = nullptr;
+					uint32_t *d_scr = nullptr;
+					auto carve = [&]() {
+						d_parents = bp->take<Parent>(np);
+						ca.start = bp->take<uint64_t>(nc);
+						ca.count = bp->take<uint64_t>(nc);
+						d_next = bp->take<Segment>(next_cap);
+						d_scr = bp->take<uint32_t>(64);
+					};
+					carve();
+					int rc = slab_reserve(c, sz.off + 4096);
+					if (!rc) rc = lists_reserve(c, (size_t)std::max(nsmall_host, ncount_host) + nc + 16, nsmall_host, ncount_host);
+					if (!rc) rc = pinned_reserve(c, std::max<size_t>(np * sizeof(Parent), 256 + 2048 * sizeof(Segment)));
+					if (rc) return rc;
+					small = c->lists;
+					small_count = c->lists + 3 * c->lists_cap;
+					Bump real(c->slab);
+					bp = &real;
+					carve();
+					hipLaunchKernelGGL(round_init_kernel, dim3(1), dim3(256), 0, c->stream, ctr, d_scr + 16, (uint64_t)0,
+							   reinterpret_cast<unsigned long long *>(d_scr + 32), (uint64_t)0, d_scr);
+					HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
+					memcpy(c->pinned, ps.data(), np * sizeof(Parent));
+					HIPCHK(c, hipMemcpyAsync(d_parents, c->pinned, np * sizeof(Parent), hipMemcpyHostToDevice, c->stream));
+					phase_mark(c, "plan+upload");
+					hipLaunchKernelGGL((regpart_kernel<V>), dim3(std::min<uint32_t>(np, (uint32_t)c->sm_count)), dim3(kRpTh), kRpLds, c->stream,
+							   (uint64_t *)keys, vals, (const Parent *)d_parents, np, ca, ctr);
+					phase_mark(c, "A register partition");
+					hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, (const Parent *)d_parents, ca, small_max, small_max,
+							   (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu), count_bits, d_next, small, small_count,
+							   HV ? (Segment *)nullptr : big, big_cap, ctr, (uint64_t *)nullptr, nc);
+					HIPCHK(c, hipGetLastError());
+					phase_mark(c, "C cleanup");
+					Counters hc;
+					const size_t ahead = std::min<size_t>(next_cap, 2048);
+					HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+					HIPCHK(c, hipMemcpyAsync((char *)c->pinned + 256, d_next, ahead * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+					HIPCHK(c, hipStreamSynchronize(c->stream));
+					memcpy(&hc, c->pinned, sizeof hc);
+					if (hc.errors) return fail(c, MSD_EINTERNAL, "register partition round: %u internal invariant violations", hc.errors);
+					nsmall_host = hc.nsmall;
+					ncount_host = hc.ncount;
+					nbig_host = hc.nbig;
+					add_stat(c, "rounds", 1);
+					add_stat(c, "regpart_rounds", 1);
+					add_stat(c, "parents", np);
+					add_stat(c, "children", nc);
+					cur = rest;
+					if (hc.next_parents) {
+						if (hc.next_parents > ahead) {
+							rc = pinned_reserve(c, (size_t)hc.next_parents * sizeof(Segment));
+							if (rc) return rc;
+							HIPCHK(c, hipMemcpyAsync(c->pinned, d_next, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+							HIPCHK(c, hipStreamSynchronize(c->stream));
+							cur.insert(cur.end(), (Segment *)c->pinned, (Segment *)c->pinned + hc.next_parents);
+						} else
+							cur.insert(cur.end(), (Segment *)((char *)c->pinned + 256), (Segment *)((char *)c->pinned + 256) + hc.next_parents);
+						std::sort(cur.begin(), cur.end(), [](const Segment &a, const Segment &b) { return a.start < b.start; });
+					}
+					phase_mark(c, "readback");
+					prev_direct = false;
+					++round;
+					continue;
+				}
+			}
+		}
 		RoundPlan rp;
 		plan_round<K, V>(cur, small_max, c->sm_count, rp, count_bits, single_pass ? sp_width : 0u, splitters ? nsplit : 0u);
 		RoundBufs rb;
@@ -868,6 +964,9 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DirectLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct2_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Direct2Lds<K, V>::bytes));
+	if constexpr (sizeof(K) == 8)
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&regpart_kernel<V>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRpLds));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
@@ -909,6 +1008,7 @@ int msd_create(msd_ctx **out, int device, void *stream)
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->sm_count = prop.multiProcessorCount;
 	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switches for benchmarks
+	if (getenv("MSD_REGPART")) c->regpart = atoi(getenv("MSD_REGPART")) != 0;
 	if (getenv("MSD_COUNT16")) c->count16 = atoi(getenv("MSD_COUNT16")); // 0 off, 1 by segment size, 2 always
 	if (getenv("MSD_DIRECT_KERNEL")) c->direct_kernel = atoi(getenv("MSD_DIRECT_KERNEL")) == 1 ? 1 : 2;
 	int rc = set_lds_attrs<uint32_t, NoVal>(c);
@@ -1236,6 +1336,8 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "direct_min")) {
 		if (value < 1) return fail(c, MSD_EINVAL, "direct_min must be positive");
 		c->direct_min = (uint64_t)value;
+	} else if (!strcmp(name, "regpart")) {
+		c->regpart = value != 0;
 	} else if (!strcmp(name, "count16")) {
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
 		c->count16 = (int)value;

@@ -62,6 +62,9 @@ out = {"lib": name, "kind": kind, "logn": logn, "ms": [round(x, 3) for x in time
        "stats": ctx.stats()}
 if hasattr(L, "msd_debug_stamps"):
     NAMES = ["scatter", "B1", "bookkeeping", "B2", "flush", "select", "waiting-keys", "B3", "-", "refill+loop", "epilogue", "tiles"]
+    if name.startswith("lstamps"):  # leaf_count_sort_kernel sections
+        NAMES = ["keys wait+OR/AND+clear", "B+merge+B", "fetch-adds", "B+sums+scan+B+prefix", "B+scatter", "descriptor+prefetch", "B+fix-up",
+                 "write-back", "-", "loop", "-", "segments"]
     if name.startswith("cstamps"):  # count_place_kernel sections
         NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
     L.msd_debug_stamps.argtypes = [C.POINTER(C.c_uint64)]
