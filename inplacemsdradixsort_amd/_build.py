@@ -13,7 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
-# diagnostic build with in-kernel cycle stamps (tools/stamps_run.py); never what tests or bench.py load
+# diagnostic build with in-kernel cycle stamps (tools/variant_run.py); never what tests or bench.py load
 STAMPS_LIB = os.path.join(HERE, "libinpmsdradix_hip_stamps.so")
 SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
 DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_count16.hpp", "msd_regpart.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
