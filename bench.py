@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2",
                     help="c2 (default) = the headline: 2^30 uniform u32; c3 Zipf; c5a/c5b pairs; u64 keys")
     ap.add_argument("--dist", choices=["uniform", "zipf"], default=None, help="(older spelling) --dist zipf = --config c3")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: REHEARSAL of the N > 1 path with all ranks on cuda:0 and the collectives staged through "
+                         "host memory (RCCL cannot run several ranks on one device); its numbers mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-logn", type=int, default=None, help="log2 tuples for the reference's 64-thread sort() "
                     "(default: 30 when the host has the memory for it, else 28)")
@@ -204,10 +207,19 @@ def main():
     N = world
     if N > 1 and cfg["dtype"] != "u32":
         raise SystemExit("the multi-GPU path shards u32 keys (configs c2 / c3)")
+    rehearsal = N > 1 and args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if N > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            import torch.distributed as tdist
+            from inplacemsdradixsort_amd.dist import HostStagedDist
+            tdist.init_process_group("gloo")
+            dist = HostStagedDist(tdist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctx = MsdContext(local_rank)
     ctx.use_torch_stream()
     n = 1 << args.logn
@@ -399,7 +411,7 @@ def main():
         "metric": headline if args.config == "c2" else f"{unit} + achieved HBM GB/s, 2^{args.logn} {cfg['title']}, 1 MI355X",
         "value": round(value, 3), "unit": unit if args.config != "c2" else "Gkeys/s", "n_gpus": N, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic",
+        "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic" + (" (REHEARSAL: gloo via host memory, all ranks on one GPU)" if rehearsal else ""),
         "config": {"workload": f"2^{args.logn} {cfg['title']} per GPU, in-place MSD radix sort, 8-bit digits"
                                + (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local sort)" if N > 1 else ""),
                    "config_id": args.config, "elements_per_gpu": n, "passes": cfg["passes_note"],

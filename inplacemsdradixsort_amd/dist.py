@@ -28,6 +28,43 @@ class ReceiveOverflow(RuntimeError):
     from the all-gathered send matrix, before the data exchange, so no rank is left in a collective)."""
 
 
+class HostStagedDist:
+    """torch.distributed's collectives for CUDA tensors over a CPU-only backend (gloo): every tensor is staged
+    through host memory.  For rehearsing the multi-rank code paths where RCCL cannot run -- several ranks sharing
+    one GPU (tests/test_gpu_dist.py, ``bench.py --backend gloo``); the real runs use backend "nccl" directly."""
+
+    def __init__(self, dist):
+        self._d = dist
+
+    def get_rank(self, group=None):
+        return self._d.get_rank(group) if group is not None else self._d.get_rank()
+
+    def barrier(self, group=None):
+        self._d.barrier(group=group)
+
+    def all_gather(self, outs, t, group=None):
+        import torch
+        tmp = [torch.empty(o.shape, dtype=o.dtype) for o in outs]
+        self._d.all_gather(tmp, t.cpu(), group=group)
+        for o, x in zip(outs, tmp):
+            o.copy_(x)
+
+    def all_reduce(self, t, op=None, group=None):
+        h = t.cpu()
+        self._d.all_reduce(h, op=op if op is not None else self._d.ReduceOp.SUM, group=group)
+        t.copy_(h)
+
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None, group=None):
+        import torch
+        o = torch.empty(output.shape, dtype=output.dtype)
+        self._d.all_to_all_single(o, input.cpu(), output_split_sizes=output_split_sizes,
+                                  input_split_sizes=input_split_sizes, group=group)
+        output.copy_(o)
+
+    def __getattr__(self, name):   # ReduceOp, get_world_size, ...
+        return getattr(self._d, name)
+
+
 def _log2(g: int) -> int:
     b = g.bit_length() - 1
     if g < 1 or (1 << b) != g or g > 256:
