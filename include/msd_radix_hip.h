@@ -8,10 +8,17 @@
  * each one names the reference function it stands in for (paths relative to
  * /root/reference).
  *
- * All d_* pointers are DEVICE pointers on the context's device.  Every call is
- * asynchronous on the context's stream unless it returns a value to the host
- * (documented per call).  Return value: 0 on success, a negative MSD_E* code
- * otherwise; msd_last_error() gives the message.
+ * All d_* pointers are DEVICE pointers on the context's device.  All kernels run on the
+ * context's stream.  msd_sort_* and msd_partition_* plan every round on the host from the
+ * previous round's child list: they block the calling thread once per round (one small
+ * device-to-host copy; two rounds for 2^30 u32 keys) and once behind the counting leaf, and
+ * return when the last kernels have been launched -- the data are final once the stream has
+ * drained.  The building blocks (histogram, scan, generators, sample, splitters) are fully
+ * asynchronous; msd_check_* are synchronous (they return values).
+ * Return value: 0 on success, a negative MSD_E* code otherwise; msd_last_error() gives the
+ * message.  After MSD_EINTERNAL (an invariant check failed between two rounds: a bug) the array
+ * holds a permutation of its input that is partitioned by the digits processed so far but not
+ * sorted; after MSD_EINVAL / MSD_ENOMEM it is untouched.
  */
 #ifndef MSD_RADIX_HIP_H_
 #define MSD_RADIX_HIP_H_
@@ -160,7 +167,11 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  * "direct_min": smallest round (elements) direct placement is tried on (default 2^26).
  * "direct_min_parent": rounds after the first: smallest parent segment (default 2^17).
  * "direct_kernel": 2 (default) = the lean direct-placement kernel (csrc/msd_direct.hpp), 1 = its
- *   first version (kept for A/B measurements). */
+ *   first version (kept for A/B measurements).
+ * "count16": u32 keys with 16 open bits: 1 (default) = count_place16_kernel for segments of about 2^14
+ *   keys, 2 = always, 0 = never (count_place_kernel).
+ * "regpart": u64 keys / tuples: 1 (default) = segments of <= 17408 elements take the register-resident
+ *   partition pass (csrc/msd_regpart.hpp) instead of a general round, 0 = never. */
 int msd_set_option(msd_ctx *ctx, const char *name, int64_t value);
 
 /* ---- phase report (reference: description[]/times[], src/msb_64.c:2402-2412) */
