@@ -84,7 +84,9 @@ int msd_histogram_u64(msd_ctx *ctx, const uint64_t *d_keys, uint64_t n,
 
 /* Device-wide exclusive prefix sum (single pass, decoupled look-back).
  * Reference: the bucket-offset prefix sums src/msb_64.c:747-750, 799-823 and
- * the cross-thread offset computation 1076-1082.  d_out may equal d_in. */
+ * the cross-thread offset computation 1076-1082.  d_out may equal d_in.  Synchronous: the call
+ * waits for the scan and returns MSD_EINTERNAL if a tile's look-back gave up (it polls a bounded
+ * number of times so that a lost predecessor cannot hang the device). */
 int msd_exclusive_scan_u64(msd_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n);
 
 /* One in-place digit pass: permute keys so that they are grouped by

@@ -1192,6 +1192,12 @@ int msd_exclusive_scan_u64(msd_ctx *c, const uint64_t *in, uint64_t *out, uint64
 	HIPCHK(c, hipMemsetAsync(state, 0, ntiles * 8, c->stream));
 	hipLaunchKernelGGL(scan_lookback_kernel, dim3((unsigned)ntiles), dim3(kScanTh), 0, c->stream, in, out, n, state, ctr, ctr + 2);
 	HIPCHK(c, hipGetLastError());
+	// the look-back gives up after a bounded number of polls and sets a flag: report it (one small readback)
+	rc = pinned_reserve(c, 64);
+	if (rc) return rc;
+	HIPCHK(c, hipMemcpyAsync(c->pinned, ctr + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	if (*(const uint32_t *)c->pinned) return fail(c, MSD_EINTERNAL, "exclusive scan: a tile's look-back timed out");
 	return MSD_OK;
 }
 
