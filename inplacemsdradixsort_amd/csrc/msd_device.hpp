@@ -62,7 +62,10 @@ template <> struct Cfg<uint64_t, NoVal> {
 };
 template <> struct Cfg<uint64_t, uint64_t> {
 	static constexpr int B = 32, T = 2048, TH = 1024;
-	static constexpr int SORT_TH = 1024, SORT_KPT = 6; // 6144
+#ifndef MSD_PAIR_LEAF_TH // (overridable for experiments)
+#define MSD_PAIR_LEAF_TH 512
+#endif
+	static constexpr int SORT_TH = MSD_PAIR_LEAF_TH, SORT_KPT = 6; // 3072 tuples: two leaf workgroups per CU (1024 threads / 6144 tuples: one, 9.2 vs 8.0 ms at 2^30)
 };
 
 struct Parent {
@@ -2120,7 +2123,7 @@ namespace msd {
 constexpr int kLeafCountBits = 14;
 // counted bits of the leaf per type: u64 keys trade one bit for a larger exchange buffer (see Cfg)
 template <typename K, typename V> struct LeafBits {
-	static constexpr int value = (sizeof(K) == 8 && !has_val<V>::value) ? 13 : kLeafCountBits;
+	static constexpr int value = (sizeof(K) == 8 && (!has_val<V>::value || Cfg<K, V>::SORT_TH < 1024)) ? 13 : kLeafCountBits;
 };
 template <typename K, typename V> struct LeafCountLds {
 	static constexpr int CAP = Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT;
