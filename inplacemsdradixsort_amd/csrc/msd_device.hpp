@@ -114,6 +114,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t leaf_ticket[2]; // work tickets of the two leaf_count_sort launches
 	uint32_t count_ticket3;  // work ticket of count_place16_kernel
 	uint32_t nslow16;        // segments count_place16_kernel left to count_place_kernel
+	uint32_t next_max;       // per round: largest next parent (saturated to 32 bits)
+	uint32_t rp_children;    // per round: children handed out by regpart_plan_kernel
 };
 static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used for 64-bit atomics");
 
@@ -1784,7 +1786,10 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 		if (at < big_cap)
 			big[at] = s; // no further round: counted and re-generated by the multi-workgroup counting sort
 		else
+		{
 			next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
+			atomicMax(&ctr->next_max, (uint32_t)(c < 0xFFFFFFFFull ? c : 0xFFFFFFFFull));
+		}
 	} else {
 		const uint32_t at = atomicAdd(&ctr->nsmall, 1u);
 		if (at < small_cap) small[at] = s; else atomicAdd(&ctr->errors, 1u);
@@ -2448,6 +2453,8 @@ __global__ __launch_bounds__(256) void round_init_kernel(Counters *__restrict__ 
 		ctr->next_parents = 0;
 		ctr->nevict = 0;
 		ctr->direct_uneven = 0;
+		ctr->next_max = 0;
+		ctr->rp_children = 0;
 		scan_ctr[0] = scan_ctr[1] = scan_ctr[2] = scan_ctr[3] = 0;
 	}
 	for (uint64_t i = i0; i < nplan_words; i += step) plan_words[i] = 0;

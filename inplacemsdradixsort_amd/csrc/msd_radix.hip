@@ -392,6 +392,7 @@ template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
 	b.take<uint8_t>(n / Cfg<K, V>::B + 2); // slot_full (direct placement)
 	b.take<Counters>(2); // counters + scratch for the varying-bit reduction
 	b.take<Segment>(n / ((uint64_t)Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT) + 16); // big counting-sort segments
+	if (sizeof(K) == 8) b.take<Segment>(n / ((uint64_t)Cfg<K, V>::SORT_TH * Cfg<K, V>::SORT_KPT + 1) + 2); // parents of a device-planned round
 	return b.off + 4096;
 }
 
@@ -463,6 +464,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	Counters *ctr = kb.take<Counters>(2);
 	const uint32_t big_cap = (uint32_t)std::min<uint64_t>(n / small_max + 16, 0x7FFFFFFFu);
 	Segment *big = kb.take<Segment>(big_cap);
+	Segment *dev_list = sizeof(K) == 8 ? kb.take<Segment>(n / (small_max + 1) + 2) : nullptr; // parents of a device-planned round
+	uint32_t dev_np = 0;
 	Segment *small = c->lists, *small_count = c->lists + 3 * c->lists_cap;
 	HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 	// keys without payload whose last <= 16 bits are open are finished by the counting sort
@@ -528,32 +531,34 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 	int round = 0;
 	bool prev_direct = false; // the previous round placed its blocks directly (its digit was evenly spread)
-	while (!cur.empty()) {
+	while (!cur.empty() || dev_np) {
 		// ---- segments that fit the registers of one workgroup take ONE register-resident pass (msd_regpart.hpp) instead
 		// of a general round: the last partition round of the tuple sort (65536 parents of about 2^14 tuples at 2^30)
 		if constexpr (sizeof(K) == 8) {
 			if (!single_pass && c->regpart) {
+				// (dev_np: the previous round left only parents that fit, and their list stayed on the device -- it is
+				// planned there too, regpart_plan_kernel; otherwise the host sorts the fitting parents out of its list)
 				std::vector<Segment> fit, rest;
-				for (auto &sg : cur) (sg.count + 1 <= kRpCap && sg.count > small_max ? fit : rest).push_back(sg);
-				if (fit.size() >= 64 || (!fit.empty() && rest.empty())) {
+				if (!dev_np)
+					for (auto &sg : cur) (sg.count + 1 <= kRpCap && sg.count > small_max ? fit : rest).push_back(sg);
+				if (dev_np || fit.size() >= 64 || (!fit.empty() && rest.empty())) {
+					const bool on_device = dev_np != 0;
 					std::vector<Parent> ps(fit.size());
 					uint32_t nc = 0;
 					for (size_t i = 0; i < fit.size(); ++i) {
 						Parent &p = ps[i];
 						p.start = fit[i].start;
 						p.count = fit[i].count;
-						// the narrowest digit whose children fit the leaf sorter with a quarter to spare (the leaf's per-segment
-						// costs favour few large segments; a child that turns out too big simply takes another pass)
-						uint32_t w = 1;
-						while (w < 8 && w < fit[i].bits && (fit[i].count >> w) > small_max - small_max / 4) ++w;
-						p.width = std::min<uint32_t>(w, fit[i].bits);
+						p.width = regpart_width(fit[i].count, fit[i].bits, small_max);
 						p.shift = fit[i].bits - p.width;
 						p.child_base = nc;
 						p.stripe_lo = p.stripe_hi = 0;
 						p.pad = 0;
 						nc += 1u << p.width;
 					}
-					const uint32_t np = (uint32_t)ps.size();
+					if (on_device) nc = dev_np << regpart_width(kRpCap, 64, small_max); // (an upper bound: the widest digit of the rule)
+					const uint32_t np = on_device ? dev_np : (uint32_t)ps.size();
+					dev_np = 0;
 					const size_t next_cap = (size_t)nc + 2; // (children above the leaf capacity: none on sane input, all at worst)
 					Bump sz(nullptr), *bp = &sz;
 					Parent *d_parents = nullptr;
@@ -570,7 +575,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					carve();
 					int rc = slab_reserve(c, sz.off + 4096);
 					if (!rc) rc = lists_reserve(c, (size_t)std::max(nsmall_host, ncount_host) + nc + 16, nsmall_host, ncount_host);
-					if (!rc) rc = pinned_reserve(c, std::max<size_t>(np * sizeof(Parent), 256 + 2048 * sizeof(Segment)));
+					if (!rc) rc = pinned_reserve(c, std::max<size_t>(on_device ? 0 : np * sizeof(Parent), 256 + 2048 * sizeof(Segment)));
 					if (rc) return rc;
 					small = c->lists;
 					small_count = c->lists + 3 * c->lists_cap;
@@ -579,9 +584,14 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					carve();
 					hipLaunchKernelGGL(round_init_kernel, dim3(1), dim3(256), 0, c->stream, ctr, d_scr + 16, (uint64_t)0,
 							   reinterpret_cast<unsigned long long *>(d_scr + 32), (uint64_t)0, d_scr);
-					HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
-					memcpy(c->pinned, ps.data(), np * sizeof(Parent));
-					HIPCHK(c, hipMemcpyAsync(d_parents, c->pinned, np * sizeof(Parent), hipMemcpyHostToDevice, c->stream));
+					if (on_device)
+						hipLaunchKernelGGL(regpart_plan_kernel, dim3((np + 255) / 256), dim3(256), 0, c->stream, (const Segment *)dev_list, np,
+								   small_max, d_parents, ctr);
+					else {
+						HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
+						memcpy(c->pinned, ps.data(), np * sizeof(Parent));
+						HIPCHK(c, hipMemcpyAsync(d_parents, c->pinned, np * sizeof(Parent), hipMemcpyHostToDevice, c->stream));
+					}
 					phase_mark(c, "plan+upload");
 					hipLaunchKernelGGL((regpart_kernel<V>), dim3(std::min<uint32_t>(np, (uint32_t)c->sm_count)), dim3(kRpTh), kRpLds, c->stream,
 							   (uint64_t *)keys, vals, (const Parent *)d_parents, np, ca, ctr);
@@ -809,7 +819,16 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		set_stat(c, "chain_steps", hc.chain_steps);
 		cur.clear();
 		if (single_pass) break;
-		if (hc.next_parents) {
+		bool stays_on_device = false;
+		if constexpr (sizeof(K) == 8) {
+			// every next parent fits a workgroup's registers: the list stays on the device and is planned there
+			if (c->regpart && hc.next_parents >= 64 && (uint64_t)hc.next_max + 1 <= kRpCap) {
+				HIPCHK(c, hipMemcpyAsync(dev_list, rb.next_parents, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToDevice, c->stream));
+				dev_np = hc.next_parents;
+				stays_on_device = true;
+			}
+		}
+		if (hc.next_parents && !stays_on_device) {
 			if (hc.next_parents <= ahead)
 				cur.assign((Segment *)((char *)c->pinned + kSegOff), (Segment *)((char *)c->pinned + kSegOff) + hc.next_parents);
 			else {

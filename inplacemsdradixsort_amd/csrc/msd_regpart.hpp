@@ -19,6 +19,35 @@ constexpr int kRpVec = 8;                                        // 16-byte vect
 constexpr uint32_t kRpCap = kRpTh * (kRpVec * 2 + 1);             // 17408 elements on the 16-byte grid (+ 1 scalar per thread)
 constexpr size_t kRpLds = (size_t)kRpCap * 8 + kP * 4 * 2 + 64 * 8 + 64; // staging | counters, starts | junk | misc
 
+// The narrowest digit whose children fit the leaf sorter with a quarter to spare (the leaf's per-segment costs favour
+// few large segments; a child that turns out too big simply takes another pass).  Host and device use the same rule.
+__host__ __device__ inline uint32_t regpart_width(uint64_t count, uint32_t bits, uint64_t small_max)
+{
+	uint32_t w = 1;
+	while (w < 8 && w < bits && (count >> w) > small_max - small_max / 4) ++w;
+	return w < bits ? w : bits;
+}
+
+// Plans a register-resident round on the device: the previous round's next-parent list -> Parent records (digit width
+// by the rule above, child ranges handed out by one fetch-add each; their order does not matter).  Saves the host the
+// round trip of the list (65536 segments at 2^30 tuples: 1.5 ms).
+__global__ __launch_bounds__(256) void regpart_plan_kernel(const Segment *__restrict__ segs, uint32_t n, uint64_t small_max,
+	Parent *__restrict__ parents, Counters *__restrict__ ctr)
+{
+	const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= n) return;
+	const Segment s = segs[i];
+	Parent p;
+	p.start = s.start;
+	p.count = s.count;
+	p.width = regpart_width(s.count, s.bits, small_max);
+	p.shift = s.bits - p.width;
+	p.child_base = atomicAdd(&ctr->rp_children, 1u << p.width);
+	p.stripe_lo = p.stripe_hi = 0;
+	p.pad = 0;
+	parents[i] = p;
+}
+
 template <typename V>
 __global__ __launch_bounds__(kRpTh, 4) void regpart_kernel(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
 	const Parent *__restrict__ parents, uint32_t nparents, ChildArrays ca, Counters *__restrict__ ctr)
