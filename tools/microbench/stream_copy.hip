@@ -162,11 +162,12 @@ template <int BLK> static void permute_suite(const char *src, char *dst, size_t 
 }
 
 // The direct classify kernel's access pattern without any of its work: 1024 workgroups (two per CU, LDS-limited like the
-// kernel), each owns a 64-slot piece of each of 256 regions; per tile it reads 128 slots (one from every second piece, pieces
-// walked from a per-piece starting offset) and writes 128 blocks into slots of the same pieces it has read earlier
-// (in place: write behind read).  What this reaches is the memory-side ceiling of that kernel.
-template <int TH, int NV>
-__global__ __launch_bounds__(TH) void pieces_kernel(char *__restrict__ data, unsigned nslots, int lag)
+// kernel), each owns a 64-slot piece of each of 256 regions; per tile it reads 128 slots (pieces walked from a per-piece
+// starting offset, SPV consecutive slots per visit of a piece) and writes 128 blocks into slots of the same pieces it has
+// read earlier (in place: write behind read; OOP: into a second buffer at the same positions).  What this reaches is the
+// memory-side ceiling of that kernel.
+template <int TH, int NV, int SPV, bool OOP>
+__global__ __launch_bounds__(TH) void pieces_kernel(char *__restrict__ data, char *__restrict__ other, unsigned nslots, int lag)
 {
 	extern __shared__ unsigned pad_lds[]; // occupancy control only
 	constexpr unsigned LPB = 16, GPW = TH / LPB, GPT = GPW * NV;
@@ -174,41 +175,43 @@ __global__ __launch_bounds__(TH) void pieces_kernel(char *__restrict__ data, uns
 	const unsigned region = nslots / 256, piece = region / W; // slots
 	const unsigned grp = threadIdx.x / LPB, sub = threadIdx.x % LPB;
 	const unsigned tiles = 256 * piece / GPT;
+	char *wbase = OOP ? other : data;
 	if (threadIdx.x == 0) pad_lds[0] = 0;
+	// running slot number j of this workgroup -> slot: visits of SPV consecutive slots, pieces round-robin
+	auto slot_of = [&](unsigned j) -> unsigned {
+		const unsigned visit = j / SPV, k = j % SPV;
+		const unsigned p = visit & 255u, idx = (visit >> 8) * SPV + k;
+		const unsigned rot = (((p * 2654435761u) ^ (me * 40503u + (me >> 3))) % piece) / SPV * SPV;
+		return p * region + me * piece + (rot + idx) % piece;
+	};
 	for (unsigned t = 0; t < tiles + lag; ++t) {
 		u32x4 v[NV];
 		unsigned long long wa[NV];
 #pragma unroll
 		for (int k = 0; k < NV; ++k) {
-			const unsigned j = t * GPT + k * GPW + grp; // running slot number of this workgroup
-			const unsigned p = j & 255u, idx = j >> 8;  // piece, index inside the piece
-			const unsigned rot = ((p * 2654435761u) ^ (me * 40503u + (me >> 3))) % piece;
-			const unsigned slot = p * region + me * piece + (rot + idx) % piece;
-			if (t < tiles) v[k] = *reinterpret_cast<const u32x4 *>(data + (size_t)slot * 256 + sub * 16);
-			// the block written now goes where this lane group read `lag` tiles ago (same piece, earlier slot)
-			const unsigned jw = j - lag * GPT, pw = jw & 255u, iw = jw >> 8;
-			const unsigned rotw = ((pw * 2654435761u) ^ (me * 40503u + (me >> 3))) % piece;
-			wa[k] = (size_t)(pw * region + me * piece + (rotw + iw) % piece) * 256 + sub * 16;
+			const unsigned j = t * GPT + k * GPW + grp;
+			if (t < tiles) v[k] = *reinterpret_cast<const u32x4 *>(data + (size_t)slot_of(j) * 256 + sub * 16);
+			wa[k] = (size_t)slot_of(j - lag * GPT) * 256 + sub * 16; // where this lane group read `lag` tiles ago
 		}
 		if (t >= (unsigned)lag) {
 #pragma unroll
-			for (int k = 0; k < NV; ++k) *reinterpret_cast<u32x4 *>(data + wa[k]) = (t < tiles) ? v[k] : u32x4{ 1, 2, 3, 4 };
+			for (int k = 0; k < NV; ++k) *reinterpret_cast<u32x4 *>(wbase + wa[k]) = (t < tiles) ? v[k] : u32x4{ 1, 2, 3, 4 };
 		}
 	}
 }
 
-template <int TH, int NV> static void run_pieces(char *data, size_t bytes, int lag, int lds_kb)
+template <int TH, int NV, int SPV, bool OOP> static void run_pieces(char *data, char *other, size_t bytes, int lag, int lds_kb)
 {
 	const unsigned nslots = (unsigned)(bytes / 256);
 	hipEvent_t e0, e1;
 	CK(hipEventCreate(&e0));
 	CK(hipEventCreate(&e1));
-	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pieces_kernel<TH, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+	CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pieces_kernel<TH, NV, SPV, OOP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
 	float best = 1e9f, sum = 0;
 	const int reps = 5;
 	for (int rep = 0; rep < reps + 1; ++rep) {
 		CK(hipEventRecord(e0));
-		hipLaunchKernelGGL((pieces_kernel<TH, NV>), dim3(1024), dim3(TH), lds_kb * 1024, 0, data, nslots, lag);
+		hipLaunchKernelGGL((pieces_kernel<TH, NV, SPV, OOP>), dim3(1024), dim3(TH), lds_kb * 1024, 0, data, other, nslots, lag);
 		CK(hipEventRecord(e1));
 		CK(hipEventSynchronize(e1));
 		float t;
@@ -218,9 +221,9 @@ template <int TH, int NV> static void run_pieces(char *data, size_t bytes, int l
 			sum += t;
 		}
 	}
-	printf("{\"kernel\": \"pieces_in_place\", \"threads\": %d, \"slots_per_thread_per_tile\": %d, \"write_lag_tiles\": %d, \"lds_KiB\": %d, "
-	       "\"best_ms\": %.3f, \"best_TBps\": %.3f, \"avg_TBps\": %.3f}\n",
-	       TH, NV, lag, lds_kb, best, 2.0 * bytes / best / 1e9, 2.0 * bytes / (sum / reps) / 1e9);
+	printf("{\"kernel\": \"pieces_%s\", \"threads\": %d, \"slots_per_thread_per_tile\": %d, \"consecutive_slots_per_piece_visit\": %d, "
+	       "\"write_lag_tiles\": %d, \"lds_KiB\": %d, \"best_ms\": %.3f, \"best_TBps\": %.3f, \"avg_TBps\": %.3f}\n",
+	       OOP ? "out_of_place" : "in_place", TH, NV, SPV, lag, lds_kb, best, 2.0 * bytes / best / 1e9, 2.0 * bytes / (sum / reps) / 1e9);
 	fflush(stdout);
 }
 
@@ -269,13 +272,15 @@ int main(int argc, char **argv)
 	run<1024, 4, false, false, 2>("write", src, dst, bytes, sink, 2);
 	run<256, 4, false, false, 2>("write", src, dst, bytes, sink, 0);
 	// ---- the direct classify kernel's in-place pattern
-	run_pieces<512, 4>((char *)src, bytes, 2, 78);
-	run_pieces<512, 4>((char *)src, bytes, 1, 78);
-	run_pieces<512, 2>((char *)src, bytes, 2, 78);
-	run_pieces<1024, 1>((char *)src, bytes, 2, 78);
-	run_pieces<1024, 2>((char *)src, bytes, 2, 78);
-	run_pieces<512, 4>((char *)src, bytes, 2, 40);
-	run_pieces<256, 4>((char *)src, bytes, 2, 40);
+	run_pieces<512, 4, 1, false>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<1024, 2, 1, false>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<512, 4, 1, true>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<512, 4, 2, false>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<512, 4, 4, false>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<512, 4, 8, false>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<512, 4, 4, true>((char *)src, (char *)dst, bytes, 2, 78);
+	run_pieces<512, 4, 1, false>((char *)src, (char *)dst, bytes, 8, 78);
+	run_pieces<256, 4, 1, false>((char *)src, (char *)dst, bytes, 2, 38);
 	// ---- block permutation (the sort's 256-byte blocks and what larger ones would buy)
 	permute_suite<128>((const char *)src, (char *)dst, bytes);
 	permute_suite<256>((const char *)src, (char *)dst, bytes);
