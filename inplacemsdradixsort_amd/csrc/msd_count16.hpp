@@ -22,9 +22,12 @@
 
 namespace msd {
 
-constexpr int kC16Th = 512;
-constexpr int kC16Vec = 8;                                   // 16-byte vectors per thread: 512 * 8 * 4 = 16384 elements
-constexpr int kC16Tail = 2;                                  // + scalar elements per thread behind them
+#ifndef MSD_C16_TH // (overridable for experiments)
+#define MSD_C16_TH 512
+#endif
+constexpr int kC16Th = MSD_C16_TH;
+constexpr int kC16Vec = 4096 / kC16Th;                       // 16-byte vectors per thread: TH * NV * 4 = 16384 elements
+constexpr int kC16Tail = 1024 / kC16Th;                      // + scalar elements per thread behind them
 constexpr uint32_t kC16Cap = kC16Th * (kC16Vec * 4 + kC16Tail); // 17408 elements on the 16-byte grid
 constexpr uint32_t kC16Words = 16384;                        // counter words (4 byte counters each)
 constexpr uint32_t kC16CwWords = kC16Words + (kC16Words >> 6) * 4; // with 4 words of padding per 64
@@ -33,11 +36,12 @@ static_assert(kC16CwWords == kC16Cap, "counters and output buffer share one LDS 
 constexpr size_t kC16Lds = (size_t)kC16Cap * 4 + kC16Th * 4 + 128 * 4 + 128;
 __device__ __forceinline__ uint32_t c16_at(uint32_t w) { return w + ((w >> 6) << 2); }
 
-__global__ __launch_bounds__(kC16Th, 4) void count_place16_kernel(uint32_t *__restrict__ keys,
+__global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place16_kernel(uint32_t *__restrict__ keys,
 	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ rejected, Counters *__restrict__ ctr,
 	uint64_t n_total)
 {
 	constexpr int TH = kC16Th, NV = kC16Vec, NT = kC16Tail, NK = NV * 4 + NT;
+	constexpr int CH = TH >= 1024 ? 4 : 8; // fetch-adds / look-ups in flight per thread (register budget: 64 or 128 VGPRs)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);  // packed byte counters (padded layout) ...
 	uint32_t *out = reinterpret_cast<uint32_t *>(smem); // ... later the output buffer, on the array's 16-byte grid
@@ -118,10 +122,10 @@ __global__ __launch_bounds__(kC16Th, 4) void count_place16_kernel(uint32_t *__re
 		if (fits) {
 			// (eight fetch-adds in flight at a time)
 #pragma unroll
-			for (int u0 = 0; u0 < NK; u0 += 8) {
-				uint32_t old[8];
+			for (int u0 = 0; u0 < NK; u0 += CH) {
+				uint32_t old[CH];
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+				for (int i = 0; i < CH; ++i) {
 					const int u = u0 + i;
 					if (u < NK) {
 						const uint32_t el = u < NV * 4 ? (uint32_t)((u / 4) * TH * 4) + tid * 4 + (u % 4) : (uint32_t)(NV * TH * 4 + (u - NV * 4) * TH) + tid;
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(kC16Th, 4) void count_place16_kernel(uint32_t *__re
 					}
 				}
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+				for (int i = 0; i < CH; ++i) {
 					const int u = u0 + i;
 					if (u < NK) rk[u] |= ((old[i] >> ((rk[u] & 3u) * 8u)) & 0xFFu) << 16;
 				}
@@ -148,17 +152,18 @@ __global__ __launch_bounds__(kC16Th, 4) void count_place16_kernel(uint32_t *__re
 		// its whole memory latency would sit in front of that prefetch)
 		const Segment nraw = segs[nxt < nsegs ? nxt : blockIdx.x];
 		// ---- the thread's 32 counter words, once: byte sums -> scan over the workgroup -> byte prefixes
-		u32x4 *cq = reinterpret_cast<u32x4 *>(cw + c16_at(tid * 32u)); // (32 t + 4 (t / 2) words: 16-byte aligned)
-		uint32_t cr[32];
+		constexpr int WPT = (int)(kC16Words / TH); // counter words per thread (32 or 16: whole 16-byte vectors, inside one 64-word group)
+		u32x4 *cq = reinterpret_cast<u32x4 *>(cw + c16_at(tid * (uint32_t)WPT)); // (16-byte aligned)
+		uint32_t cr[WPT];
 		uint32_t totk = 0;
 		if (fits) {
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
+			for (int j = 0; j < WPT / 4; ++j) {
 				const u32x4 q = cq[j];
 				cr[4 * j + 0] = q.x; cr[4 * j + 1] = q.y; cr[4 * j + 2] = q.z; cr[4 * j + 3] = q.w;
 			}
 #pragma unroll
-			for (int j = 0; j < 32; ++j) totk = __builtin_amdgcn_sad_u8(cr[j], 0u, totk);
+			for (int j = 0; j < WPT; ++j) totk = __builtin_amdgcn_sad_u8(cr[j], 0u, totk);
 		}
 		if (totk > 255u) *crowded = 1; // (a byte prefix would not fit)
 		const uint32_t inc = wave_incl_scan(totk);
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(kC16Th, 4) void count_place16_kernel(uint32_t *__re
 		if (ok) {
 			uint32_t run = 0;
 #pragma unroll
-			for (int j = 0; j < 8; ++j) {
+			for (int j = 0; j < WPT / 4; ++j) {
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					const uint32_t x = cr[4 * j + e], y = x * 0x01010101u; // bytes of y: inclusive sums inside the word
@@ -193,18 +198,18 @@ __global__ __launch_bounds__(kC16Th, 4) void count_place16_kernel(uint32_t *__re
 			// ---- place of every key: base[owner of its value] + prefix[value] + rank
 			// (the place, < 2^15, replaces the rank in bits 16..30)
 #pragma unroll
-			for (int u0 = 0; u0 < NK; u0 += 8) {
-				uint32_t tb[8], cv[8];
+			for (int u0 = 0; u0 < NK; u0 += CH) {
+				uint32_t tb[CH], cv[CH];
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+				for (int i = 0; i < CH; ++i) {
 					if (u0 + i < NK) {
 						const uint32_t wi = (rk[u0 + i] & 0xFFFFu) >> 2;
-						tb[i] = tbase[wi >> 5];
+						tb[i] = tbase[wi / (uint32_t)WPT];
 						cv[i] = cw[c16_at(wi)];
 					}
 				}
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
+				for (int i = 0; i < CH; ++i) {
 					if (u0 + i < NK) {
 						const uint32_t r = rk[u0 + i];
 						const uint32_t pl = tb[i] + ((cv[i] >> ((r & 3u) * 8u)) & 0xFFu) + ((r >> 16) & 0xFFu);
