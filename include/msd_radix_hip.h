@@ -168,8 +168,8 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  *   Rounds after the first follow (from exact per-parent digit counts) if the first round did.
  * "direct_min": smallest round (elements) direct placement is tried on (default 2^26).
  * "direct_min_parent": rounds after the first: smallest parent segment (default 2^17).
- * "direct_kernel": 2 (default) = the lean direct-placement kernel (csrc/msd_direct.hpp), 1 = its
- *   first version (kept for A/B measurements).
+ * "direct_kernel": accepted and ignored (round 1's first version of the direct kernel is gone;
+ *   profiles/r02_sq_counters.json and r02_stamps_classify_direct_before.json keep its measurements).
  * "count16": u32 keys with 16 open bits: 1 (default) = count_place16_kernel for segments of about 2^14
  *   keys, 2 = always, 0 = never (count_place_kernel).
  * "regpart": u64 keys / tuples: 1 (default) = segments of <= 17408 elements take the register-resident

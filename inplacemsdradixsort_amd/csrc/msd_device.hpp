@@ -17,7 +17,7 @@
 //                        the hole and inherits the vacated slot.
 //   C  cleanup_kernel    bucket heads/tails are filled from the stripes'
 //                        partial buffers.
-//   A' classify_direct_kernel (rounds whose buckets are about equally big and free of
+//   A' classify_direct2_kernel, msd_direct.hpp (rounds whose buckets are about equally big and free of
 //                        runs): bucket boundaries are known before the pass (sampled /
 //                        exactly counted), every workgroup reads its own share of each
 //                        bucket's region and writes completed blocks straight into it,
@@ -573,8 +573,8 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 
 // ------------------------------------ A': classify with direct block placement
 
-// Experimental variant of phase A for a single large parent whose children are about equally big.
-// A strided sample estimates the child boundaries; every workgroup owns, for each child, a *piece*
+// Variant of phase A for parents whose children are about equally big (the kernel itself: msd_direct.hpp).
+// A strided sample (first round) or an exact count estimates the child boundaries; every workgroup owns, for each child, a *piece*
 // (run of slots) of that child's estimated region and reads its pieces round-robin, one 256-byte
 // slot per piece per row.  A completed block goes straight into the workgroup's own piece of the
 // block's child whenever that piece has a slot that was already read ("write behind read" holds
@@ -721,20 +721,6 @@ __global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restri
 	if (d == 0 && (runs || !(s_mn > 0 && (double)s_mx <= 1.25 * (double)s_mn))) atomicAdd(&ctr->direct_uneven, 1u);
 }
 
-template <typename K, typename V> struct DirectLds {
-	using C = Cfg<K, V>;
-	static constexpr bool HV = has_val<V>::value;
-	static constexpr size_t kbuf = (size_t)(kP * C::B) * sizeof(K);
-	static constexpr size_t vbuf = HV ? (size_t)(kP * C::B) * sizeof(uint64_t) : 0;
-	static constexpr size_t head = (size_t)2 * C::B * sizeof(K) + (HV ? (size_t)2 * C::B * sizeof(uint64_t) : 0);
-	static constexpr int JOBS = kP; // at most one buffer per bucket and tile
-	static constexpr int XT = 128;
-	static constexpr int SEL = 64; // slots read per tile (upper bound over the configurations)
-	// meta, cnt, hc, loff, plo, cw, pnl, bst, fbc, rot : 10*kP u32 ; jobs (2 words each) ; xtab ; sel ; tmp
-	static constexpr size_t small = (size_t)(10 * kP + 2 * JOBS + 2 * XT + SEL + 32) * sizeof(uint32_t);
-	static constexpr size_t bytes = kbuf + vbuf + head + small;
-};
-
 // The `need` lanes with the smallest 10-bit value among the eligible ones (ties: lower lane first).
 // Wave-uniform radix select on ballots; returns this lane's verdict, `mask_out` = all selected lanes.
 __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int need, uint64_t &mask_out)
@@ -760,397 +746,6 @@ __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int 
 		selm = cand;
 	mask_out = selm;
 	return lane_bit(selm);
-}
-
-template <typename K, typename V>
-__global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<V>::value ? 4 : 8) : 1)) void classify_direct_kernel(
-	K *__restrict__ keys, uint64_t *__restrict__ vals, const Stripe *__restrict__ stripes,
-	const Parent *__restrict__ parents, const DirectPlan *__restrict__ plans, uint8_t *__restrict__ block_map,
-	uint8_t *__restrict__ slot_full, uint32_t *__restrict__ fb, uint32_t *__restrict__ lo_cnt,
-	uint32_t *__restrict__ lo_off, K *__restrict__ lo_keys, uint64_t *__restrict__ lo_vals,
-	uint32_t *__restrict__ nfull, Counters *__restrict__ ctr, uint32_t force)
-{
-	if (!force && ctr->direct_uneven) return; // the plan declined: the streaming kernel behind this launch runs instead
-	using C = Cfg<K, V>;
-	constexpr bool HV = has_val<V>::value;
-	constexpr int B = C::B, TH = C::TH;
-	constexpr int VEC = Vec16<K>::N;
-	constexpr int LPB = B / VEC;       // lanes per slot (16)
-	constexpr int GPT = TH / LPB;      // slots read per tile (64 for 1024 threads)
-	constexpr int SPW = GPT / 4;       // slots each of the 4 bucket waves may request per tile
-	constexpr int KPT = VEC;           // one 16-byte vector per thread per tile
-	constexpr int PB = kP * B;
-	constexpr uint32_t NONE = 0xFFFFFFFFu;
-	static_assert(GPT % 4 == 0 && GPT <= DirectLds<K, V>::SEL, "tile geometry");
-	using L = DirectLds<K, V>;
-
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	// the small arrays come first: their LDS addresses then fit the 16-bit offset field of the DS
-	// instructions (one address register for all of them)
-	uint32_t *meta = reinterpret_cast<uint32_t *>(smem);
-	uint64_t *headv = reinterpret_cast<uint64_t *>(smem + L::small);
-	K *headk = reinterpret_cast<K *>(smem + L::small + (HV ? (size_t)2 * B * sizeof(uint64_t) : 0));
-	K *kbuf = reinterpret_cast<K *>(smem + L::small + L::head);
-	uint64_t *vbuf = reinterpret_cast<uint64_t *>(smem + L::small + L::head + L::kbuf);
-	uint32_t *cnt = meta + kP;
-	uint32_t *hc = cnt + kP;
-	uint32_t *loff = hc + kP;
-	uint32_t *plo = loff + kP;     // first slot of my piece of child d
-	uint32_t *cw = plo + kP;       // slots of the piece consumed (low 16) | blocks written into it (high 16)
-	uint32_t *pnl = cw + kP;       // slots in the piece
-	uint32_t *bst = pnl + kP;      // bucket state: reads issued (low 16) | in-flight bits (16..17) | buffer fill (18..)
-	uint32_t *fbc = bst + kP;      // full blocks produced
-	uint32_t *rot = fbc + kP;      // the piece is used from slot rot[d] on, wrapping around (see phys)
-	uint32_t *jobs = rot + kP;     // [2*g] bucket, [2*g+1] destination slot
-	uint32_t *xtab = jobs + 2 * L::JOBS; // (bucket<<16 | q) -> slot for the extra blocks of skewed tiles
-	uint32_t *sel = xtab + 2 * L::XT;    // slots to read for the tile after next
-	uint32_t *tmp = sel + L::SEL;  // [0..1] jobs per tile (ping-pong) [2..3] xtab fill [6..7] steal flag [12..15] reads selected [8..] scan scratch (epilogue)
-
-	const uint32_t tid = threadIdx.x, grp = tid / LPB, sub = tid % LPB, lane = tid & 63;
-	const Stripe st = stripes[blockIdx.x];
-	const Parent pa = parents[st.parent];
-	const uint32_t shift = pa.shift, mask = (1u << pa.width) - 1u;
-	const uint32_t W = pa.stripe_hi - pa.stripe_lo, me = blockIdx.x - pa.stripe_lo;
-	const DirectPlan *plan = plans + st.parent;
-	const uint32_t slot0 = plan->bound[0], slotN = plan->bound[kP];
-
-	// per-bucket state lives in LDS (thread d < kP is the only one to touch bst/fbc of bucket d)
-	if (tid < kP) {
-		const uint32_t b0 = plan->bound[tid], b1 = plan->bound[tid + 1], len = b1 - b0;
-		const uint32_t p0 = b0 + (uint32_t)((uint64_t)me * len / W);
-		plo[tid] = p0;
-		pnl[tid] = b0 + (uint32_t)((uint64_t)(me + 1) * len / W) - p0;
-		// All workgroups advance through their pieces at about the same pace.  Were every piece used
-		// from its first slot on, the addresses in flight at any moment would agree in the bits that
-		// select the memory channel; a per-piece starting offset spreads them over all channels.
-		const uint32_t pn0 = b0 + (uint32_t)((uint64_t)(me + 1) * len / W) - p0;
-		rot[tid] = pn0 ? ((tid * 2654435761u) ^ (me * 40503u + (me >> 3))) % pn0 : 0u;
-		bst[tid] = 0;
-		fbc[tid] = 0;
-		cw[tid] = 0;
-		meta[tid] = 0;
-		cnt[tid] = 0;
-		hc[tid] = 0;
-	}
-	if (tid < 32) tmp[tid] = 0;
-	// head / tail keys of the parent (outside every aligned slot): first / last workgroup parks them
-	const uint64_t pend = pa.start + pa.count;
-	uint32_t h = 0;
-	if (me == 0) {
-		h = (uint32_t)((uint64_t)slot0 * B - pa.start);
-		if (tid < h) {
-			headk[tid] = keys[pa.start + tid];
-			if (HV) headv[tid] = vals[pa.start + tid];
-		}
-	}
-	uint32_t h2 = 0;
-	if (me == W - 1) {
-		h2 = (uint32_t)(pend - (uint64_t)slotN * B);
-		if (tid < h2) {
-			headk[h + tid] = keys[(uint64_t)slotN * B + tid];
-			if (HV) headv[h + tid] = vals[(uint64_t)slotN * B + tid];
-		}
-	}
-	const uint32_t hh = h + h2;
-	__syncthreads();
-	if (tid < hh) atomicAdd(&hc[digit_of(headk[tid], shift, mask)], 1u);
-	// A block written into piece d holds bucket d unless it was stolen by another bucket: mark the
-	// whole piece up front (64-byte runs), the rare stolen slot is overwritten when it is handed out;
-	// which slots hold a block at all (the first `written` of each piece) is recorded at the end.
-	for (uint32_t d = tid >> 6; d < (uint32_t)kP; d += TH / 64) {
-		const uint32_t p0 = plo[d], pn = pnl[d];
-		for (uint32_t j = lane; j < pn; j += 64) block_map[p0 + j] = (uint8_t)d;
-	}
-
-	// idx-th slot of piece d in the order the piece is used
-	auto phys = [&](uint32_t d, uint32_t idx) -> uint32_t {
-		const uint32_t pn = pnl[d];
-		uint32_t j = rot[d] + idx;
-		if (j >= pn) j -= pn;
-		return plo[d] + j;
-	};
-	// Which slots to read next: the pieces whose buckets have the least room (read-ahead slots plus
-	// free buffer space) go first, so that a bucket's next slot has been read before its buffer fills.
-	auto select_reads = [&](uint32_t wr, uint32_t rd, uint32_t q, uint32_t fill, uint32_t *count_out) {
-		const bool elig = rd < pnl[tid];
-		const uint32_t v = min(1023u, (rd - wr) * B + B - fill);
-		uint64_t sm;
-		const bool mine = wave_select_smallest(v, elig, SPW, sm);
-		// the wave's slice of sel[]: a scalar (wave-uniform) base, so that no per-lane address is kept
-		// in a register across the tile loop (the compiler spills such invariants, and a reload behind
-		// the outstanding prefetch waits for it)
-		const uint32_t n = (uint32_t)__popcll(sm);
-		uint32_t *selw = sel + __builtin_amdgcn_readfirstlane(tid >> 6) * SPW;
-		if (mine) {
-			selw[popc_below_lane(sm)] = phys(tid, rd);
-			++rd;
-			q |= 2; // bit0: has a slot in the next tile, bit1: in the tile after it
-		}
-		const uint32_t l = popc_below_lane(~0ull); // = lane id
-		if (l < (uint32_t)SPW && l >= n) selw[l] = NONE;
-		if (l == 0 && n) atomicAdd(count_out, n);
-		bst[tid] = rd | (q << 16) | (fill << 18);
-	};
-	auto load_tile = [&](K *kr, uint64_t *vr) -> bool {
-		const uint32_t slot = sel[grp];
-		const bool ok = slot >= slot0 && slot < slotN; // NONE fails the test
-		if (ok) {
-			const uint64_t at = (uint64_t)slot * B + sub * VEC;
-			if constexpr (sizeof(K) == 4) {
-				const uint4 q = *reinterpret_cast<const uint4 *>(keys + at);
-				kr[0] = q.x; kr[1] = q.y; kr[2] = q.z; kr[3] = q.w;
-			} else {
-				const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(keys + at);
-				kr[0] = q.x; kr[1] = q.y;
-			}
-			if constexpr (HV) {
-				const ulonglong2 q = *reinterpret_cast<const ulonglong2 *>(vals + at);
-				vr[0] = q.x; vr[1] = q.y;
-			}
-		}
-		return ok;
-	};
-
-	K kreg[KPT], kregB[KPT];
-	uint64_t vreg[HV ? KPT : 1], vregB[HV ? KPT : 1];
-	K dkey[KPT];
-	uint64_t dval[HV ? KPT : 1];
-	uint32_t dat[KPT];
-#pragma unroll
-	for (int i = 0; i < KPT; ++i) dat[i] = NONE;
-
-	// prologue: the first two tiles
-	if (tid < kP) {
-		select_reads(0, 0, 0, 0, &tmp[14]);
-		bst[tid] = (bst[tid] & 0xFFFFu) | (((bst[tid] >> 17) & 1u) << 16); // -> bit0: in tile 0
-	}
-	__syncthreads();
-	uint32_t nA = tmp[14];
-	bool okA = load_tile(kreg, vreg);
-	__syncthreads();
-	if (tid < kP) select_reads(0, bst[tid] & 0xFFFFu, (bst[tid] >> 16) & 3u, 0, &tmp[15]); // bit1: in tile 1
-	__syncthreads();
-	uint32_t nB = tmp[15];
-	bool okB = load_tile(kregB, vregB);
-	uint32_t par = 0;
-
-	MSD_STAMP_DECL(1);
-	MSD_STAMP_START();
-	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1], bool &okc, uint32_t &nc) {
-		MSD_STAMP(9); // flush of the previous tile + loop overhead
-		MSD_STAMP_TICK(11);
-		// ---- ranks
-		uint32_t dr[KPT];
-#pragma unroll
-		for (int i = 0; i < KPT; ++i) {
-			dr[i] = NONE;
-			if (okc) {
-				const uint32_t d = digit_of(kc[i], shift, mask);
-				dr[i] = d | (atomicAdd(&cnt[d], 1u) << 8);
-			}
-		}
-		MSD_STAMP(0); // ranks (incl. the wait for this tile's keys)
-		__syncthreads(); // B1
-		MSD_STAMP(1); // barrier B1
-		// ---- per bucket: completed blocks take a consumed slot of the bucket's own piece if there is one
-		uint32_t pend_blocks = 0, own_r = 0, sel_state = 0;
-		if (tid < kP) {
-			const uint32_t bs = bst[tid], fill0 = bs >> 18;
-			uint32_t q_r = (bs >> 16) & 3u;
-			const uint32_t L_r = fill0 + cnt[tid];
-			cnt[tid] = 0;
-			const uint32_t nb_r = L_r / B;
-			const uint32_t cwv = cw[tid], wr = cwv >> 16;
-			const uint32_t cons = (cwv & 0xFFFFu) + (q_r & 1u); // this tile's slot is now in registers
-			q_r >>= 1;
-			uint32_t own = 0;
-			if (nb_r) {
-				own = min(nb_r, cons - wr); // consecutive own slots plo+wr .. plo+wr+own-1
-				if (own) { // block 0 = the LDS buffer
-					const uint32_t j = atomicAdd(&tmp[par], 1u);
-					jobs[2 * j] = tid;
-					jobs[2 * j + 1] = phys(tid, wr);
-				}
-				pend_blocks = nb_r - own;
-				if (pend_blocks) tmp[6 + par] = 1;
-				fbc[tid] += nb_r;
-			}
-			cw[tid] = cons | ((wr + own) << 16);
-			meta[tid] = fill0 | (nb_r << 8) | (own << 20);
-			loff[tid] = wr; // first own destination (index into the piece) of this tile
-			own_r = own;
-			sel_state = (bs & 0xFFFFu) | (q_r << 16) | ((L_r - nb_r * B) << 18); // reads issued | in flight | new fill
-		}
-		if (tid == 0) {
-			tmp[par ^ 1] = 0;
-			tmp[2 + (par ^ 1)] = 0;
-			tmp[6 + (par ^ 1)] = 0;
-			tmp[12 + (par ^ 1)] = 0;
-		}
-		MSD_STAMP(2); // per-bucket bookkeeping
-		__syncthreads(); // B2a
-		MSD_STAMP(3); // barrier B2a
-		if (tmp[6 + par]) { // (uniform) some bucket has no consumed slot left in its own piece: take one of another piece
-			for (uint32_t q = 0; q < pend_blocks; ++q) {
-				uint32_t slot = NONE, e = (tid * 37u + 1u) & (kP - 1);
-				for (uint32_t tries = 0; tries < 3 * kP; ++tries, e = (e + 1) & (kP - 1)) {
-					const uint32_t c0 = cw[e];
-					if ((c0 >> 16) >= (c0 & 0xFFFFu)) continue;
-					const uint32_t old = atomicAdd(&cw[e], 1u << 16);
-					if ((old >> 16) < (old & 0xFFFFu)) {
-						slot = phys(e, old >> 16);
-						break;
-					}
-					atomicSub(&cw[e], 1u << 16);
-				}
-				const uint32_t bi = own_r + q; // block index within this tile's run of the bucket
-				if (slot == NONE)
-					atomicAdd(&ctr->errors, 1u); // cannot happen: consumed slots >= blocks produced
-				else if (slot < slot0 || slot >= slotN)
-					atomicAdd(&ctr->errors, 1u);
-				else if (bi == 0) { // the bucket's LDS buffer
-					const uint32_t j = atomicAdd(&tmp[par], 1u);
-					jobs[2 * j] = tid;
-					jobs[2 * j + 1] = slot;
-					block_map[slot] = (uint8_t)tid;
-				} else {
-					const uint32_t x = atomicAdd(&tmp[2 + par], 1u);
-					if (x < (uint32_t)L::XT) {
-						uint32_t tq = tid;
-						asm volatile("" : "+v"(tq)); // keep (tid << 16) out of the loop-invariant registers
-						xtab[2 * x] = (tq << 16) | bi;
-						xtab[2 * x + 1] = slot;
-						block_map[slot] = (uint8_t)tid;
-					} else
-						atomicAdd(&ctr->errors, 1u);
-				}
-			}
-			__syncthreads(); // B2b
-		}
-		MSD_STAMP(4); // steals + B2b
-		// the next reads are chosen after the barrier: the other twelve waves scatter meanwhile
-		// (the choice is needed only when the next tile's loads are issued, after B3)
-		if (tid < kP) select_reads(cw[tid] >> 16, sel_state & 0xFFFFu, (sel_state >> 16) & 3u, sel_state >> 18, &tmp[12 + par]);
-		MSD_STAMP(5); // read selection
-		const uint32_t nx = min(tmp[2 + par], (uint32_t)L::XT);
-		const uint32_t njobs = tmp[par];
-		// ---- scatter
-#pragma unroll
-		for (int i = 0; i < KPT; ++i) {
-			if (dat[i] != NONE) {
-				kbuf[dat[i]] = dkey[i];
-				if constexpr (HV) vbuf[dat[i]] = dval[i];
-				dat[i] = NONE;
-			}
-		}
-#pragma unroll
-		for (int i = 0; i < KPT; ++i) {
-			if (dr[i] != NONE) {
-				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
-				const uint32_t m = meta[d];
-				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
-				if (nb == 0 || vp < (uint32_t)B) {
-					kbuf[d * B + vp] = kc[i];
-					if constexpr (HV) vbuf[d * B + vp] = vc[i];
-				} else if (vp < nb * B) { // skewed tile: a further whole block of this bucket
-					const uint32_t q = vp / B, own = m >> 20;
-					uint32_t slot;
-					if (q < own)
-						slot = phys(d, loff[d] + q);
-					else {
-						slot = NONE;
-						for (uint32_t x = 0; x < nx; ++x)
-							if (xtab[2 * x] == ((d << 16) | q)) slot = xtab[2 * x + 1];
-					}
-					if (slot >= slot0 && slot < slotN) {
-						const uint64_t at = (uint64_t)slot * B + (vp - q * B);
-						keys[at] = kc[i];
-						if constexpr (HV) vals[at] = vc[i];
-					} else
-						atomicAdd(&ctr->errors, 1u);
-				} else {
-					dat[i] = d * B + vp - nb * B;
-					dkey[i] = kc[i];
-					if constexpr (HV) dval[i] = vc[i];
-				}
-			}
-		}
-		MSD_STAMP(6); // scatter
-		__syncthreads(); // B3
-		MSD_STAMP(7); // barrier B3
-		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only (measured: leaving it to the compiler costs 0.1 ms per launch)
-		MSD_STAMP(8); // vmcnt(0): the previous flush's stores (and the loads issued a tile ago)
-		nc = tmp[12 + par];
-		okc = load_tile(kc, vc);
-		// ---- flush completed buffers to their slots
-		for (uint32_t g = grp; g < njobs; g += GPT) {
-			const uint32_t d = jobs[2 * g], slot = jobs[2 * g + 1];
-			if (slot >= slot0 && slot < slotN) {
-				const uint64_t dst = (uint64_t)slot * B + sub * VEC;
-				*reinterpret_cast<uint4 *>(keys + dst) = *reinterpret_cast<const uint4 *>(kbuf + d * B + sub * VEC);
-				if constexpr (HV)
-					*reinterpret_cast<uint4 *>(vals + dst) = *reinterpret_cast<const uint4 *>(vbuf + d * B + sub * VEC);
-			} else if (sub == 0)
-				atomicAdd(&ctr->errors, 1u);
-		}
-		par ^= 1;
-	};
-	for (;;) {
-		if (!nA) break;
-		tile(kreg, vreg, okA, nA);
-		if (!nB) break;
-		tile(kregB, vregB, okB, nB);
-	}
-	__syncthreads();
-	MSD_STAMP(9);
-#pragma unroll
-	for (int i = 0; i < KPT; ++i) {
-		if (dat[i] != NONE) {
-			kbuf[dat[i]] = dkey[i];
-			if constexpr (HV) vbuf[dat[i]] = dval[i];
-		}
-	}
-	uint32_t fill_r = 0;
-	if (tid < kP) {
-		fill_r = bst[tid] >> 18;
-		meta[tid] = fill_r;
-	}
-	__syncthreads();
-	// ---- epilogue: leftovers (partial buffers + head/tail keys) to the side area
-	uint32_t lc = 0;
-	if (tid < kP) lc = fill_r + hc[tid];
-	uint32_t ltot;
-	const uint32_t lex = block_excl_scan256(lc, tmp + 8, ltot);
-	const size_t so = (size_t)blockIdx.x * kP + tid;
-	if (tid < kP) {
-		loff[tid] = lex;
-		lo_cnt[so] = lc;
-		lo_off[so] = lex;
-		fb[so] = fbc[tid];
-		hc[tid] = 0;
-	}
-	if (tid == 0) nfull[blockIdx.x] = 0;
-	__syncthreads();
-	for (uint32_t d = tid >> 6; d < (uint32_t)kP; d += TH / 64) {
-		const uint32_t p0 = plo[d], pn = pnl[d], wr = cw[d] >> 16, r0 = rot[d];
-		for (uint32_t j = lane; j < pn; j += 64) slot_full[p0 + j] = (j >= r0 ? j - r0 : j + pn - r0) < wr ? 1 : 0;
-	}
-	for (uint32_t idx = tid; idx < (uint32_t)PB; idx += TH) {
-		const uint32_t d = idx / B, j = idx % B;
-		if (j < (meta[d] & 0xFFu)) {
-			lo_keys[st.lo_base + loff[d] + j] = kbuf[idx];
-			if constexpr (HV) lo_vals[st.lo_base + loff[d] + j] = vbuf[idx];
-		}
-	}
-	if (tid < hh) {
-		const uint32_t d = digit_of(headk[tid], shift, mask);
-		const uint32_t r = atomicAdd(&hc[d], 1u);
-		const uint64_t at = st.lo_base + loff[d] + (meta[d] & 0xFFu) + r;
-		lo_keys[at] = headk[tid];
-		if constexpr (HV) lo_vals[at] = headv[tid];
-	}
-	MSD_STAMP(10); // epilogue
-	MSD_STAMP_FLUSH(TH / 64);
 }
 
 } // namespace msd

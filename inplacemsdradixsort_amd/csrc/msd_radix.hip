@@ -53,7 +53,6 @@ struct msd_ctx {
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
-	int direct_kernel = 2; // 1: first version of the direct classify kernel (A/B comparisons), 2: msd_direct.hpp
 };
 
 static int fail(msd_ctx *c, int code, const char *fmt, ...)
@@ -711,12 +710,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			// launched behind it if it is zero.  The host learns it with the round's summary.
 			tried_direct = true;
 			const uint32_t force = c->direct_mode == 2 ? 1u : 0u;
-			if (c->direct_kernel == 1) {
-				constexpr size_t direct_lds = DirectLds<K, V>::bytes;
-				hipLaunchKernelGGL((classify_direct_kernel<K, V>), dim3(ns), dim3(C::TH), direct_lds, c->stream,
-						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
-						   rb.fb, rb.lo_cnt, rb.lo_off, (K *)rb.lo_keys, rb.lo_vals, rb.nfull, ctr, force);
-			} else {
+			{
 				constexpr size_t direct_lds = Direct2Lds<K, V>::bytes;
 				hipLaunchKernelGGL((classify_direct2_kernel<K, V>), dim3(ns), dim3(Direct2Cfg<K, V>::TH), direct_lds, c->stream,
 						   keys, vals, rb.stripes, rb.parents, (const DirectPlan *)rb.plans, block_map, slot_full,
@@ -981,8 +975,6 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ClassifyLds<K, V>::bytes + kP * sizeof(K))));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
-	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct_kernel<K, V>),
-				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)DirectLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct2_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Direct2Lds<K, V>::bytes));
 	if constexpr (sizeof(K) == 8)
@@ -1031,7 +1023,6 @@ int msd_create(msd_ctx **out, int device, void *stream)
 	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switches for benchmarks
 	if (getenv("MSD_REGPART")) c->regpart = atoi(getenv("MSD_REGPART")) != 0;
 	if (getenv("MSD_COUNT16")) c->count16 = atoi(getenv("MSD_COUNT16")); // 0 off, 1 by segment size, 2 always
-	if (getenv("MSD_DIRECT_KERNEL")) c->direct_kernel = atoi(getenv("MSD_DIRECT_KERNEL")) == 1 ? 1 : 2;
 	int rc = set_lds_attrs<uint32_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, uint64_t>(c);
@@ -1369,8 +1360,7 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
 		c->count16 = (int)value;
 	} else if (!strcmp(name, "direct_kernel")) {
-		if (value < 1 || value > 2) return fail(c, MSD_EINVAL, "direct_kernel must be 1 or 2");
-		c->direct_kernel = (int)value;
+		(void)value; // (round 1's kernel is gone; the option is accepted for old callers)
 	} else if (!strcmp(name, "direct_min_parent")) {
 		if (value < 1) return fail(c, MSD_EINVAL, "direct_min_parent must be positive");
 		c->direct_min_parent = (uint64_t)value;

@@ -52,7 +52,6 @@ for c in range(cases):
     mode = int(torch.randint(0, 3, (1,)).item())
     ctx.set_option("direct_mode", mode)
     if not os.environ.get("SOAK_DEFAULT_OPTS"):
-        ctx.set_option("direct_kernel", 1 + int(torch.randint(0, 4, (1,)).item() != 0))   # mostly the current kernel
         ctx.set_option("count16", int(torch.randint(0, 3, (1,)).item()))
         ctx.set_option("regpart", int(torch.randint(0, 4, (1,)).item() != 0))
         ctx.set_option("direct_min", 1 << int(torch.randint(14, 27, (1,)).item()))
