@@ -1,0 +1,98 @@
+"""Every kernel variant a tuning knob selects gives the oracle's result: the specialised 16-bit counting leaf
+(count16 = 0 / 1 / 2), the register-resident partition round (regpart = 0 / 1), direct placement on and off --
+so that A/B switches used for measurements cannot hide a wrong path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx():
+    from inplacemsdradixsort_amd import MsdContext
+    c = MsdContext(0)
+    yield c
+    c.close()
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int32 if a.dtype == np.uint32 else np.int64)).cuda()
+
+
+def host(t):
+    a = t.cpu().numpy()
+    return a.view(np.uint32) if a.dtype == np.int32 else a.view(np.uint64)
+
+
+@pytest.mark.parametrize("count16", [0, 1, 2])
+@pytest.mark.parametrize("n,kind", [((1 << 22) + 5, "uniform"), (1 << 24, "uniform"), ((1 << 23) + 3, "dup"), (3_000_001, "zipf")])
+def test_count16_modes(ctx, count16, n, kind):
+    """u32 keys whose leaves have 16 open bits: the same result whichever counting leaf takes them (segments of 2^6 ..
+    2^14 keys, duplicates that overflow byte counters, segments starting at any element)."""
+    k = {"uniform": lambda: O.gen_uniform_u32(n, seed=41), "zipf": lambda: O.gen_zipf_u32(n, seed=42),
+         "dup": lambda: O.gen_dup_u32(n, 5000, seed=43)}[kind]()
+    ctx.set_option("count16", count16)
+    ctx.set_option("direct_min", 1 << 20)
+    t = dev(k)
+    ctx.sort_u32(t)
+    assert (host(t) == np.sort(k)).all()
+    # a sub-array that starts 16 bytes into the allocation and ends on an odd element
+    t2 = dev(k)
+    ctx.sort_u32(t2[4:n - 3])
+    assert (host(t2[4:n - 3]) == np.sort(k[4:n - 3])).all() and (host(t2[:4]) == k[:4]).all() and (host(t2[n - 3:]) == k[n - 3:]).all()
+
+
+@pytest.mark.parametrize("regpart", [0, 1])
+@pytest.mark.parametrize("n,shr", [(300_001, 0), ((1 << 21) + 7, 0), (1 << 22, 40), (4_000_000, 0)])
+def test_regpart_modes_pairs(ctx, regpart, n, shr):
+    """(key, rid) tuples whose last partition round has parents of a few thousand tuples: with and without the
+    register-resident pass the key sequence is the oracle's and the rids follow their keys."""
+    import torch
+    k = O.gen_uniform_u64(n, seed=51) >> np.uint64(shr)
+    ctx.set_option("regpart", regpart)
+    tk = dev(k)
+    tr = torch.arange(n, dtype=torch.int64, device="cuda")
+    ctx.sort_pairs_u64(tk, tr)
+    out, rid = host(tk), tr.cpu().numpy()
+    assert (out == np.sort(k)).all()
+    assert (k[rid] == out).all() and (np.sort(rid) == np.arange(n)).all()
+    st = ctx.stats()
+    if regpart == 0:
+        assert st.get("regpart_rounds", 0) == 0
+    elif n == 4_000_000:
+        assert st.get("regpart_rounds", 0) >= 1, st   # the first round leaves 256 parents of about 15.6 Ki tuples: they fit
+
+
+@pytest.mark.parametrize("regpart", [0, 1])
+def test_regpart_modes_u64_keys(ctx, regpart):
+    k = O.gen_uniform_u64(3_000_003, seed=52)
+    ctx.set_option("regpart", regpart)
+    t = dev(k)
+    ctx.sort_u64(t)
+    assert (host(t) == np.sort(k)).all()
+
+
+def test_last_error_of_the_reference_api_is_empty_after_a_good_sort():
+    import ctypes as C
+    import inplacemsdradixsort_amd as M
+    from inplacemsdradixsort_amd import _lib
+    n = 50_000
+    k = O.gen_uniform_u64(n, seed=53)
+    keys = [M.mamalloc(n * 8).view(np.uint64)]
+    rids = [M.mamalloc(n * 8).view(np.uint64)]
+    keys[0][:] = k
+    rids[0][:] = k
+    size = [n]
+    M.sort(keys, rids, size, threads=64, numa=1, fudge=1.0)
+    L = _lib.load()
+    L.msb_64_last_error.restype = C.c_char_p
+    assert L.msb_64_last_error() == b"" and (keys[0] == np.sort(k)).all() and size == [n]
