@@ -343,6 +343,7 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 	rb.ca.rot = b.take<uint32_t>(nc);
 	rb.ca.nev = b.take<uint32_t>(nc);
 	rb.ca.xfirst = b.take<uint32_t>(nc);
+	rb.ca.hot_cur = b.take<uint32_t>((size_t)kHotMax * kHotShards * kRposStride);
 	rb.list = b.take<ListEntry>(rp.nslots + 1);
 	// holes: tail slots (< kP + 2 per stripe) + one eviction + one excess per child
 	// + the eviction pool: what it takes to reach kMinChains chains (shared out in proportion to the list
