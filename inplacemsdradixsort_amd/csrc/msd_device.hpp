@@ -23,7 +23,7 @@
 //                        bucket's region and writes completed blocks straight into it,
 //                        so that B only moves the few misplaced blocks.
 // Leaves: count_place_kernel / count_walk_kernel (keys only, <= 16 open bits: one counting
-// pass over all of them), bigcount_* (the same for segments of any size),
+// pass over all of them), bigcount_* (the same for segments of any size, msd_bigcount.hpp),
 // leaf_count_sort_kernel (everything else that fits LDS: one counting pass over the top
 // varying bits + group fix-up), lds_sort_kernel (general fallback: stable LSD passes
 // inside LDS; ranks from wavefront ballot/popcount match-any).
@@ -2009,88 +2009,9 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 	MSD_STAMP_FLUSH(TH / 64);
 }
 
-// ------------------------------------- counting sort for segments of any size
-
-// Keys-only segments with <= 16 open bits that do not fit LDS: every tile of a segment counts its
-// values in LDS (16-bit counters, a tile has < 65536 keys) and adds them to the segment's global
-// histogram; a scan turns counts into positions; every output tile is then re-generated from the
-// prefix array (value-parallel, long runs filled by whole waves) and stored coalesced.  One read and
-// one write of the segment replace all remaining partition rounds, whatever the key distribution.
-struct BigTile {
-	uint64_t off;  // first element of the tile, relative to the segment
-	uint32_t len;  // elements (<= kBigTile)
-	uint32_t seg;  // index into the big-segment list
-};
-constexpr uint32_t kBigTile = 32768;       // keys per tile: 128 KiB of LDS staging for u32
-constexpr uint32_t kBigRun = 32;           // longer runs are filled cooperatively
-constexpr uint32_t kBigHeavyCap = 1024;
-constexpr size_t kBigHistLds = 32768 * 4;  // 2^15 32-bit counters (half of the value range per pass)
-constexpr uint32_t kBigChunk = 1u << 22;   // keys per histogram workgroup
-constexpr size_t kBigWriteLds = (size_t)kBigTile * 4 + kBigHeavyCap * 12 + 64;
-
-template <typename K>
-__global__ __launch_bounds__(1024) void bigcount_hist_kernel(const K *__restrict__ keys,
-	const Segment *__restrict__ segs, const BigTile *__restrict__ chunks, uint32_t *__restrict__ ghist)
-{
-	// 32-bit LDS counters for half of the 2^16 value range: a chunk of millions of keys is read once
-	// per half (twice in all), so the merge into the segment's global histogram -- one coalesced
-	// atomic add per counter -- is negligible per key.
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint32_t *cw = reinterpret_cast<uint32_t *>(smem);
-	const BigTile ch = chunks[blockIdx.x];
-	const Segment sg = segs[ch.seg];
-	const uint32_t nv = 1u << sg.bits, mask = nv - 1u, tid = threadIdx.x;
-	const uint32_t half = nv > 32768u ? 32768u : nv;
-	const K *src = keys + sg.start + ch.off;
-	uint32_t *gh = ghist + (size_t)ch.seg * 65536;
-	bool hot = false; // (wave-uniform)
-	for (uint32_t base = 0; base < nv; base += half) {
-		for (uint32_t j = tid; j < half; j += 1024) cw[j] = 0;
-		__syncthreads();
-		for (uint32_t i0 = 0; i0 < ch.len; i0 += 4 * 1024) {
-			K k4[4];
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint32_t idx = i0 + u * 1024 + tid;
-				k4[u] = idx < ch.len ? src[idx] : (K)0;
-			}
-#pragma unroll
-			for (int u = 0; u < 4; ++u) {
-				const uint32_t idx = i0 + u * 1024 + tid;
-				const uint32_t v = ((uint32_t)k4[u] & mask) - base;
-				bool mine = idx < ch.len && v < half;
-				if (hot) {
-					// heavily repeated values (low-cardinality keys): lanes that share a value take ONE
-					// fetch-add together -- a same-address LDS atomic serialises per lane.  Tried only
-					// while the previous batch found such a value.
-					hot = false;
-#pragma unroll
-					for (int r = 0; r < 4; ++r) {
-						const uint64_t todo = __ballot(mine);
-						if (!todo) break;
-						const int l = __ffsll((long long)todo) - 1;
-						const uint32_t vl = (uint32_t)__shfl((int)v, l);
-						const uint64_t same = __ballot(mine && v == vl);
-						if (__popcll(same) < 4) break;
-						if ((int)(tid & 63) == l) atomicAdd(&cw[vl], (uint32_t)__popcll(same));
-						if (v == vl) mine = false;
-						hot = true;
-					}
-				} else if (u == 0) { // probe: does the first lane's value repeat in this wave?
-					const uint32_t vl = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-					hot = __popcll(__ballot(mine && v == vl)) >= 4;
-				}
-				if (mine) atomicAdd(&cw[v], 1u);
-			}
-		}
-		__syncthreads();
-		for (uint32_t j = tid; j < half; j += 1024) {
-			const uint32_t c = cw[j];
-			if (c) atomicAdd(&gh[base + j], c);
-		}
-		__syncthreads();
-	}
-}
+} // namespace msd
+#include "msd_bigcount.hpp"
+namespace msd {
 
 // One launch clears what a round starts from (a handful of separate memsets cost a few microseconds of
 // idle GPU each): the per-round counters, the per-parent plans of a direct round, the scan's tile state.
@@ -2111,114 +2032,6 @@ __global__ __launch_bounds__(256) void round_init_kernel(Counters *__restrict__ 
 	}
 	for (uint64_t i = i0; i < nplan_words; i += step) plan_words[i] = 0;
 	for (uint64_t i = i0; i < ntiles; i += step) scan_state[i] = 0;
-}
-
-// counts -> exclusive prefix (in place); also records the segment's common key prefix.
-// Wave w owns the contiguous values [w*nv/16, (w+1)*nv/16) and walks them 64 at a time (coalesced).
-template <typename K>
-__global__ __launch_bounds__(1024) void bigcount_scan_kernel(const K *__restrict__ keys,
-	const Segment *__restrict__ segs, uint32_t *__restrict__ ghist, K *__restrict__ seg_hi, Counters *__restrict__ ctr)
-{
-	__shared__ uint32_t wtot[16];
-	const Segment sg = segs[blockIdx.x];
-	const uint32_t nv = 1u << sg.bits, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	uint32_t *gh = ghist + (size_t)blockIdx.x * 65536;
-	const uint32_t per = (nv + 15) / 16;                  // values per wave
-	const uint32_t v0 = w * per, v1 = v0 + per < nv ? v0 + per : nv;
-	uint32_t tot = 0;
-	for (uint32_t v = v0 + lane; v < v1; v += 64) tot += gh[v];
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-	if (lane == 0) wtot[w] = tot;
-	__syncthreads();
-	uint32_t run = 0;
-	for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
-	for (uint32_t vb = v0; vb < v1; vb += 64) {
-		const uint32_t v = vb + lane;
-		const uint32_t c = v < v1 ? gh[v] : 0u;
-		const uint32_t inc = wave_incl_scan(c);
-		if (v < v1) gh[v] = run + inc - c;
-		run += __shfl(inc, 63);
-	}
-	if (w == 15 && lane == 0) {
-		if (run != (uint32_t)sg.count) atomicAdd(&ctr->errors, 1u); // every key was counted exactly once
-		const K mask = (K)nv - 1;
-		seg_hi[blockIdx.x] = keys[sg.start] & ~mask;
-	}
-}
-
-template <typename K>
-__global__ __launch_bounds__(1024) void bigcount_write_kernel(K *__restrict__ keys,
-	const Segment *__restrict__ segs, const BigTile *__restrict__ tiles, const uint32_t *__restrict__ ghist,
-	const K *__restrict__ seg_hi)
-{
-	constexpr uint32_t TILE = kBigTile * 4 / sizeof(K); // elements staged per workgroup
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	K *stage = reinterpret_cast<K *>(smem);
-	uint32_t *heavy = reinterpret_cast<uint32_t *>(smem + (size_t)kBigTile * 4); // (value, begin, count) triples
-	uint32_t *misc = heavy + kBigHeavyCap * 3;                                    // [0] v_lo [1] v_hi [2] nheavy
-	const BigTile tl = tiles[blockIdx.x];
-	const Segment sg = segs[tl.seg];
-	const uint32_t nv = 1u << sg.bits, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-	const uint32_t *P = ghist + (size_t)tl.seg * 65536; // exclusive prefix per value
-	const K hi = seg_hi[tl.seg];
-	const uint32_t total = (uint32_t)sg.count;
-	for (uint32_t sub = 0; sub < tl.len; sub += TILE) { // (u64 keys stage half a tile at a time)
-		const uint32_t off = (uint32_t)tl.off + sub;
-		const uint32_t len = tl.len - sub < TILE ? tl.len - sub : TILE;
-		if (w == 0) {
-			// v_lo: last value whose run starts at or before `off`; v_hi: last value whose run starts
-			// before off+len.  64-ary search: every lane probes one position per step (3 steps for 2^16).
-			auto last_le = [&](uint32_t target, uint32_t lo0) {
-				uint32_t lo = lo0, range = nv - lo0; // invariant: P[lo] <= target (P[0] = 0), answer in [lo, lo+range)
-				while (range > 1) {
-					const uint32_t step = (range + 63) / 64;
-					const uint32_t idx = lo + lane * step;
-					const bool ok = lane * step < range && P[idx] <= target;
-					const uint64_t m = __ballot(ok);
-					const uint32_t top = 63u - (uint32_t)__builtin_clzll(m | 1ull);
-					lo += top * step;
-					range = range - top * step < step ? range - top * step : step;
-				}
-				return lo;
-			};
-			const uint32_t a = last_le(off, 0);
-			const uint32_t b2 = last_le(off + len - 1, a);
-			if (lane == 0) {
-				misc[0] = a;
-				misc[1] = b2;
-				misc[2] = 0;
-			}
-		}
-		__syncthreads();
-		const uint32_t v_lo = misc[0], v_hi = misc[1];
-		for (uint32_t v = v_lo + tid; v <= v_hi; v += 1024) {
-			const uint32_t pb = P[v], pe = v + 1 < nv ? P[v + 1] : total;
-			const uint32_t b = pb > off ? pb : off, e = pe < off + len ? pe : off + len;
-			if (e > b) {
-				const K kv = hi | (K)v;
-				if (e - b <= kBigRun) {
-					for (uint32_t i = b; i < e; ++i) stage[i - off] = kv;
-				} else {
-					const uint32_t at = atomicAdd(&misc[2], 1u);
-					heavy[3 * at] = v;
-					heavy[3 * at + 1] = b - off;
-					heavy[3 * at + 2] = e - b;
-				}
-			}
-		}
-		__syncthreads();
-		const uint32_t nheavy = misc[2];
-		for (uint32_t hidx = w; hidx < nheavy; hidx += 16) {
-			const K kv = hi | (K)heavy[3 * hidx];
-			const uint32_t s0 = heavy[3 * hidx + 1], c = heavy[3 * hidx + 2];
-			for (uint32_t i = lane; i < c; i += 64) stage[s0 + i] = kv;
-		}
-		__syncthreads();
-		K *dst = keys + sg.start + off;
-		for (uint32_t i = tid; i < len; i += 1024) dst[i] = stage[i];
-		__syncthreads();
-	}
 }
 
 // ------------------------------------------------------- LDS segment sort

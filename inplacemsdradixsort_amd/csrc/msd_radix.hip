@@ -890,36 +890,47 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			const uint32_t batch_max = 4096; // 256 KiB of histogram per segment: 1 GiB per batch
 			for (uint32_t b0 = 0; b0 < nbig_host; b0 += batch_max) {
 				const uint32_t nb = std::min(batch_max, nbig_host - b0);
-				std::vector<BigTile> tiles; // first the histogram chunks, then the output tiles
-				for (uint32_t i = 0; i < nb; ++i)
-					for (uint64_t off = 0; off < bs[b0 + i].count; off += kBigChunk)
-						tiles.push_back({ off, (uint32_t)std::min<uint64_t>(kBigChunk, bs[b0 + i].count - off), i });
-				const size_t nchunks = tiles.size();
-				for (uint32_t i = 0; i < nb; ++i)
-					for (uint64_t off = 0; off < bs[b0 + i].count; off += kBigTile)
-						tiles.push_back({ off, (uint32_t)std::min<uint64_t>(kBigTile, bs[b0 + i].count - off), i });
-				Bump sz(nullptr);
-				sz.take<uint32_t>((size_t)nb * 65536);
-				sz.take<K>(nb);
-				sz.take<BigTile>(tiles.size());
+				// work items -> segments: first[i] = index of segment i's first histogram chunk / group of output tiles
+				constexpr uint32_t tile_elems = big_tile_elems<K>() * kBigGroup;
+				std::vector<uint32_t> first(2 * ((size_t)nb + 1));
+				uint32_t *first_chunk = first.data(), *first_tile = first.data() + nb + 1;
+				uint64_t nchunks = 0, ntiles = 0;
+				for (uint32_t i = 0; i < nb; ++i) {
+					first_chunk[i] = (uint32_t)nchunks;
+					first_tile[i] = (uint32_t)ntiles;
+					nchunks += (bs[b0 + i].count + kBigChunk - 1) / kBigChunk;
+					ntiles += (bs[b0 + i].count + tile_elems - 1) / tile_elems;
+				}
+				first_chunk[nb] = (uint32_t)nchunks;
+				first_tile[nb] = (uint32_t)ntiles;
+				uint32_t *ghist = nullptr, *d_first = nullptr;
+				K *seg_hi = nullptr;
+				uint16_t *tile_v = nullptr;
+				Bump sz(nullptr), *bp = &sz;
+				auto carve = [&]() {
+					ghist = bp->take<uint32_t>((size_t)nb * 65536);
+					seg_hi = bp->take<K>(nb);
+					d_first = bp->take<uint32_t>(first.size());
+					tile_v = bp->take<uint16_t>(ntiles * kBigGroup + nb + 8);
+				};
+				carve();
 				rc = slab_reserve(c, sz.off + 4096); // the round slab is dead by now
-				if (!rc) rc = pinned_reserve(c, tiles.size() * sizeof(BigTile));
+				if (!rc) rc = pinned_reserve(c, first.size() * sizeof(uint32_t));
 				if (rc) return rc;
 				Bump bb(c->slab);
-				uint32_t *ghist = bb.take<uint32_t>((size_t)nb * 65536);
-				K *seg_hi = bb.take<K>(nb);
-				BigTile *dchunks = bb.take<BigTile>(tiles.size());
-				BigTile *dtiles = dchunks + nchunks;
+				bp = &bb;
+				carve();
 				HIPCHK(c, hipStreamSynchronize(c->stream));
-				memcpy(c->pinned, tiles.data(), tiles.size() * sizeof(BigTile));
-				HIPCHK(c, hipMemcpyAsync(dchunks, c->pinned, tiles.size() * sizeof(BigTile), hipMemcpyHostToDevice, c->stream));
+				memcpy(c->pinned, first.data(), first.size() * sizeof(uint32_t));
+				HIPCHK(c, hipMemcpyAsync(d_first, c->pinned, first.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
 				HIPCHK(c, hipMemsetAsync(ghist, 0, (size_t)nb * 65536 * sizeof(uint32_t), c->stream));
-				hipLaunchKernelGGL((bigcount_hist_kernel<K>), dim3((unsigned)nchunks), dim3(1024), kBigHistLds, c->stream,
-						   (const K *)keys, big + b0, dchunks, ghist);
+				hipLaunchKernelGGL((bigcount_hist_kernel<K>), dim3((unsigned)std::min<uint64_t>(nchunks, (uint64_t)c->sm_count)), dim3(kBigHistTh), kBigHistLds, c->stream,
+						   (const K *)keys, big + b0, (const uint32_t *)d_first, nb, ghist);
 				hipLaunchKernelGGL((bigcount_scan_kernel<K>), dim3(nb), dim3(1024), 0, c->stream,
-						   (const K *)keys, big + b0, ghist, seg_hi, ctr);
-				hipLaunchKernelGGL((bigcount_write_kernel<K>), dim3((unsigned)(tiles.size() - nchunks)), dim3(1024), kBigWriteLds, c->stream,
-						   keys, big + b0, dtiles, (const uint32_t *)ghist, (const K *)seg_hi);
+						   (const K *)keys, big + b0, (const uint32_t *)(d_first + nb + 1), ghist, seg_hi, tile_v, ctr);
+				hipLaunchKernelGGL((bigcount_write_kernel<K>), dim3((unsigned)ntiles), dim3(kBigWriteTh), kBigWriteLds, c->stream,
+						   keys, big + b0, (const uint32_t *)(d_first + nb + 1), nb, (const uint32_t *)ghist, (const K *)seg_hi,
+						   (const uint16_t *)tile_v);
 				HIPCHK(c, hipGetLastError());
 			}
 			phase_mark(c, "big count sort");

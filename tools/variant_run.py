@@ -2,7 +2,7 @@
 """Time one sort of 2^logn uniform u32 keys with an experimental build of the library
 (inplacemsdradixsort_amd._build.build_variant / build_stamps) and print its phase table.
 
-    python tools/variant_run.py <library suffix, e.g. "stamps" or "v1"> [logn] [u32|u64|pairs]
+    python tools/variant_run.py <library suffix, e.g. "stamps" or "v1"> [logn] [u32|zipf|u64|pairs]
 """
 import ctypes as C
 import json
@@ -29,6 +29,14 @@ if kind == "u32":
     t = torch.empty(n, dtype=torch.int32, device="cuda")
     gen = lambda s: ctx.gen_uniform_u32(t, seed=0x5EED0001 + s)
     run = lambda: ctx.sort_u32(t)
+elif kind == "zipf":
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    gen = lambda s: ctx.gen_zipf_u32(t, seed=0x5EED0003 + s)
+    run = lambda: ctx.sort_u32(t)
+elif kind.startswith("dup"):  # dup<distinct>: that many distinct values
+    t = torch.empty(n, dtype=torch.int32, device="cuda")
+    gen = lambda s: ctx.gen_dup_u32(t, int(kind[3:]), seed=0x5EED0004 + s)
+    run = lambda: ctx.sort_u32(t)
 elif kind == "u64":
     t = torch.empty(n, dtype=torch.int64, device="cuda")
     gen = lambda s: ctx.gen_uniform_u64(t, seed=0x5EED0005 + s)
@@ -53,7 +61,7 @@ for it in range(4):
     torch.cuda.synchronize()
     times.append(e0.elapsed_time(e1))
     c1 = ctx.check(t)
-    assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
+    assert os.environ.get("MSD_VARIANT_NOCHECK") or (c1[0] == 0 and c1[1:] == c0[1:]), (c0, c1)  # (timing-only experiments)
 gen(9)
 ctx.set_profiling(True)
 run()
@@ -67,6 +75,10 @@ if hasattr(L, "msd_debug_stamps"):
                  "write-back", "-", "loop", "-", "segments"]
     if name.startswith("cstamps"):  # count_place_kernel sections
         NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
+    if name.startswith("wstamps"):  # bigcount_write_kernel sections
+        NAMES = ["look-ups", "tile inside one run", "2 barriers", "runs of the tile", "B+long runs", "B", "LDS->array", "-", "-", "-", "fast tiles", "tiles"]
+    if name.startswith("hstamps"):  # bigcount_hist_kernel sections
+        NAMES = ["chunk set-up", "load issue", "counting", "merge", "-", "-", "-", "-", "-", "-", "-", "chunks"]
     L.msd_debug_stamps.argtypes = [C.POINTER(C.c_uint64)]
     buf = (C.c_uint64 * 32)()
     ctx.set_profiling(False)
@@ -79,7 +91,7 @@ if hasattr(L, "msd_debug_stamps"):
     for w, label in ((0, "wave0"), (1, "last_wave")):
         v = [int(buf[w * 16 + i]) for i in range(12)]
         tiles = max(1, v[11])
-        out[label] = {f"{i}:{NAMES[i]}": round(v[i] / tiles, 1) for i in range(11) if NAMES[i] != "-"}
+        out[label] = {f"{i}:{NAMES[i]}": round(v[i] / tiles, 1 if v[i] / tiles < 1e4 else 0) for i in range(11) if NAMES[i] != "-"}
         out[label]["cycles_per_tile"] = round(sum(v[:11]) / tiles, 1)
         out[label]["tiles"] = v[11]
 print(json.dumps(out))
