@@ -125,7 +125,7 @@ static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used
 // -DMSD_STAMPS (tools/stamps_build.sh, never the shipped library): wave 0 (a "bucket wave") and the last wave of
 // every classify_direct workgroup add the shader cycles they spend in each section of the tile loop to
 // g_stamps[which wave][section]; read back with msd_debug_stamps().
-#ifdef MSD_STAMPS // = 1: classify_direct kernels, 2: count_place kernels, 3: leaf_count_sort_kernel
+#ifdef MSD_STAMPS // = 1: classify_direct kernels, 2: count_place kernels, 3: leaf_count_sort_kernel, 4/5: bigcount write/hist, 6: classify_kernel
 __device__ unsigned long long g_stamps[2][16];
 #define MSD_STAMP_DECL(id)                          \
 	constexpr bool kStampThis = MSD_STAMPS == (id); \
@@ -271,7 +271,7 @@ template <typename K, typename V> struct ClassifyLds {
 	static constexpr size_t head = (size_t)C::B * sizeof(K) + (HV ? (size_t)C::B * sizeof(uint64_t) : 0);
 	static constexpr int JOBS = kP + 8;
 	// meta, cnt, hc, loff : 4*kP u32 ; jobs ; tmp 16
-	static constexpr size_t small = (size_t)(4 * kP + JOBS + 16) * sizeof(uint32_t);
+	static constexpr size_t small = (size_t)(4 * kP + JOBS + 16 + 64 + 64) * sizeof(uint32_t);
 	static constexpr size_t bytes = kbuf + vbuf + head + small;
 };
 
@@ -312,7 +312,9 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	uint32_t *hc = cnt + kP;     // head keys per bucket
 	uint32_t *loff = hc + kP;    // leftover offsets
 	uint32_t *jobs = loff + kP;  // flush job table: bucket whose buffer goes to slot wslot+g
-	uint32_t *tmp = jobs + L::JOBS; // [0..1] slots claimed per tile (ping-pong), [2..3] buffer-flush jobs, [4..] scan scratch
+	uint32_t *tmp = jobs + L::JOBS; // [0..1] slots | jobs << 16 claimed per tile (ping-pong), [4..7] scan scratch, [8..9] skew
+	uint32_t *multi = tmp + 16;     // buckets that completed more than one block in this tile: bucket | blocks << 8 | first slot << 16
+	uint32_t *spare = multi + 64;   // a word per lane that only ever receives zeros
 	K *spl = reinterpret_cast<K *>(smem + L::bytes); // RANGE only: the delimiters (the launch adds kP keys of LDS)
 
 	const uint32_t tid = threadIdx.x;
@@ -339,6 +341,7 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 		hc[tid] = 0;
 	}
 	if (tid < 16) tmp[tid] = 0;
+	if (tid < 64) spare[tid] = 0;
 	const uint64_t a0 = (uint64_t)st.slot_lo * B; // first aligned position >= begin
 	// ---- head keys (only a parent's first stripe has them): parked in LDS until the end
 	const uint32_t h = (uint32_t)((a0 < st.end ? a0 : st.end) - st.begin);
@@ -401,6 +404,8 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	if (pos < st.end) load_tile(pos, kreg, vreg);
 	if (pos + T < st.end) load_tile(pos + T, kregB, vregB);
 	uint32_t par = 0; // tile parity: which pair of claim counters is live
+	MSD_STAMP_DECL(6);
+	MSD_STAMP_START();
 
 	// One tile: [ranks] B1 [per-bucket bookkeeping] B2 [scatter] B3 [prefetch tile t+2 into the
 	// registers this tile just vacated] [flush].  Two register sets alternate (no copies), so a load
@@ -410,12 +415,39 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 	auto tile = [&](K (&kc)[KPT], uint64_t (&vc)[HV ? KPT : 1]) {
 		const uint64_t npos = pos + T;
 		const bool full = npos <= st.end;                  // uniform: every key of the tile exists
+		MSD_STAMP(9);
+		MSD_STAMP_TICK(11);
 
 		// ---- rank every key inside its bucket for this tile (LDS fetch-add)
 		uint32_t dr[KPT]; // digit | rank<<8
-		if (full && tmp[8 + (par ^ 1)]) {
-			// the previous tile was skewed: lanes that share lane 0's digit take ONE fetch-add together
-			// (a same-address LDS atomic serialises per lane)
+		const uint32_t hflag = tmp[8 + (par ^ 1)];
+		if (full && hflag && sizeof(K) == 4) {
+			// the previous tile was skewed -- bucket hflag - 1 took more than a sixteenth of it: the lanes of a wave that
+			// hold a key of that bucket take ONE fetch-add together (a same-address LDS atomic serialises per lane), their
+			// first lane for all of them.  Branch-free, all fetch-adds of the tile before the first result is looked at:
+			// a lane whose key is counted by another one adds zero to its own spare word.
+			const uint32_t h = hflag - 1u;
+			uint32_t old[KPT];
+			uint64_t hm[KPT];
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) {
+				const uint32_t d = digit_of(kc[i], shift, mask);
+				hm[i] = __ballot(d == h);
+				const bool rides = d == h && popc_below_lane(hm[i]) != 0;
+				uint32_t *at = rides ? spare + lane_id() : cnt + d;
+				old[i] = atomicAdd(at, rides ? 0u : (d == h ? (uint32_t)__popcll(hm[i]) : 1u));
+				dr[i] = d;
+			}
+			__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) {
+				const int lead = hm[i] ? __ffsll((long long)hm[i]) - 1 : 0;
+				const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)old[i], lead);
+				dr[i] |= (dr[i] == h ? base + popc_below_lane(hm[i]) : old[i]) << 8;
+			}
+		} else if (full && hflag) {
+			// (8-byte keys: the batched form above spills at this kernel's register budget) lanes that share lane 0's
+			// digit take one fetch-add together
 #pragma unroll
 			for (int i = 0; i < KPT; ++i) {
 				const uint32_t d = digit_of(kc[i], shift, mask);
@@ -449,20 +481,26 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 				}
 			}
 		}
+		MSD_STAMP(0); // ranks (incl. the wait for the keys)
 		__syncthreads(); // B1
+		MSD_STAMP(1);
 
 		// ---- per bucket: blocks completed by this tile claim consecutive output slots
 		if (tid < kP) {
 			const uint32_t ct = cnt[tid];
-			if (ct > (uint32_t)T / 16) tmp[8 + par] = 1; // skewed tile: the next one aggregates equal digits per wave
+			if (ct > (uint32_t)T / 16) tmp[8 + par] = 1u + tid; // skewed tile: the next one counts this bucket's keys per wave
 			const uint32_t L_r = fill_r + ct;
 			cnt[tid] = 0;
 			const uint32_t nb_r = L_r / B;
 			uint32_t bbase = 0;
 			if (nb_r) {
-				bbase = atomicAdd(&tmp[par], nb_r);            // slots wslot+bbase .. +nb_r-1
-				jobs[atomicAdd(&tmp[2 + par], 1u)] = tid | (bbase << 8); // the bucket's LDS buffer becomes block 0
-				for (uint32_t q = 1; q < nb_r; ++q) block_map[wslot + bbase + q] = (uint8_t)tid; // (skewed tiles only)
+				// ONE fetch-add claims the slots wslot+bbase .. +nb_r-1 (low half) and a place in the job table (high half);
+				// the bucket's LDS buffer becomes the first block, further ones (skewed tiles only) are written straight
+				// from registers; the flush writes the map entries of all of them
+				const uint32_t claim = atomicAdd(&tmp[par], nb_r | 0x10000u);
+				bbase = claim & 0xFFFFu;
+				jobs[claim >> 16] = tid | (bbase << 8);
+				if (nb_r > 1) multi[atomicAdd(&tmp[10 + par], 1u)] = tid | (nb_r << 8) | (bbase << 16);
 			}
 			meta[tid] = fill_r | (nb_r << 8) | (bbase << 20);
 			fill_r = L_r - nb_r * B;
@@ -470,11 +508,13 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 		}
 		if (tid == 0) { // the other parity's counters were last read before B1
 			tmp[par ^ 1] = 0;
-			tmp[2 + (par ^ 1)] = 0;
 			tmp[8 + (par ^ 1)] = 0;
+			tmp[10 + (par ^ 1)] = 0;
 		}
+		MSD_STAMP(2); // bookkeeping
 		__syncthreads(); // B2
-		const uint32_t nbtot = tmp[par], njobs = tmp[2 + par];
+		MSD_STAMP(3);
+		const uint32_t nbtot = tmp[par] & 0xFFFFu, njobs = tmp[par] >> 16, nmulti = tmp[10 + par];
 
 		// ---- scatter: first the remainders deferred from the previous tile, then this tile's keys
 #pragma unroll
@@ -485,11 +525,16 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 				dat[i] = 0xFFFFFFFFu;
 			}
 		}
+		uint32_t mt[KPT]; // (all look-ups before the first use: one LDS round trip, not one per key)
+		if constexpr (sizeof(K) == 4) { // (8-byte keys: spills at this kernel's register budget)
+#pragma unroll
+			for (int i = 0; i < KPT; ++i) mt[i] = meta[dr[i] & 0xFFu];
+		}
 #pragma unroll
 		for (int i = 0; i < KPT; ++i) {
 			if (dr[i] != 0xFFFFFFFFu) {
 				const uint32_t d = dr[i] & 0xFFu, r = dr[i] >> 8;
-				const uint32_t m = meta[d];
+				const uint32_t m = sizeof(K) == 4 ? mt[i] : meta[d];
 				const uint32_t vp = (m & 0xFFu) + r, nb = (m >> 8) & 0xFFFu;
 				if (nb == 0 || vp < (uint32_t)B) { // tops up the bucket's buffer
 					kbuf[d * B + vp] = kc[i];
@@ -505,31 +550,41 @@ __global__ __launch_bounds__((Cfg<K, V>::TH), (Cfg<K, V>::TH >= 1024 ? (has_val<
 				}
 			}
 		}
+		MSD_STAMP(4); // scatter
 		__syncthreads(); // B3
+		MSD_STAMP(5);
 
 		// ---- everything outstanding is a tile old: drain it, then refill the vacated registers
 		__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) only
+		MSD_STAMP(6); // drain
 		if (npos + T < st.end) load_tile(npos + T, kc, vc);
+		MSD_STAMP(7); // refill issue
 
 		// ---- flush the completed buffers to their slots behind the read cursor
 		for (uint32_t g = tid / LPB; g < njobs; g += TH / LPB) {
-			const uint32_t j = jobs[g];
+			const uint32_t j = jobs[g], slot = j >> 8;
 			const uint32_t src = (j & 0xFFu) * B + (tid % LPB) * VEC;
-			const uint64_t dst = (uint64_t)(wslot + (j >> 8)) * B + (tid % LPB) * VEC;
+			const uint64_t dst = (uint64_t)(wslot + slot) * B + (tid % LPB) * VEC;
 			*reinterpret_cast<uint4 *>(keys + dst) = *reinterpret_cast<const uint4 *>(kbuf + src);
 			if constexpr (HV)
 				*reinterpret_cast<uint4 *>(vals + dst) = *reinterpret_cast<const uint4 *>(vbuf + src);
-			if ((tid % LPB) == 0) block_map[wslot + (j >> 8)] = (uint8_t)(j & 0xFFu);
+			if ((tid % LPB) == 0) block_map[wslot + slot] = (uint8_t)(j & 0xFFu);
+		}
+		for (uint32_t e = 0; e < nmulti; ++e) { // (skewed tiles only) the map entries of a bucket's further blocks
+			const uint32_t m = multi[e], nb = (m >> 8) & 0xFFu;
+			for (uint32_t q = tid; q + 1u < nb; q += TH) block_map[wslot + (m >> 16) + 1u + q] = (uint8_t)(m & 0xFFu);
 		}
 		wslot += nbtot;
 		pos = npos;
 		par ^= 1;
+		MSD_STAMP(8); // flush
 	};
 	while (pos < st.end) {
 		tile(kreg, vreg);
 		if (pos >= st.end) break;
 		tile(kregB, vregB);
 	}
+	MSD_STAMP_FLUSH(TH / 64);
 	__syncthreads();
 	// remainders deferred by the last tile
 #pragma unroll

@@ -75,6 +75,8 @@ if hasattr(L, "msd_debug_stamps"):
                  "write-back", "-", "loop", "-", "segments"]
     if name.startswith("cstamps"):  # count_place_kernel sections
         NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
+    if name.startswith("sstamps"):  # classify_kernel (streaming) sections
+        NAMES = ["ranks", "B1", "bookkeeping", "B2", "scatter", "B3", "drain", "refill issue", "flush", "loop", "-", "tiles"]
     if name.startswith("wstamps"):  # bigcount_write_kernel sections
         NAMES = ["look-ups", "tile inside one run", "2 barriers", "runs of the tile", "B+long runs", "B", "LDS->array", "-", "-", "-", "fast tiles", "tiles"]
     if name.startswith("hstamps"):  # bigcount_hist_kernel sections
