@@ -1239,6 +1239,11 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 	const uint32_t shard0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) % kHotShards;
 	uint32_t tries = 0;
 
+	// The first 64 holes of every wave are its own, by position: one fetch-add per wave on the one cursor word would be
+	// most of this kernel's time when there are few holes (direct placement: 2.6e5 holes for 8192 waves, 0.15 ms of
+	// claims at the rate a single word takes them).  The cursor hands out what lies behind those.
+	const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	bool first = true;
 	for (;;) {
 		// ---- lanes without a hole fetch the next chain start
 		if (!exhausted) {
@@ -1246,9 +1251,13 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 			if (need) {
 				const uint32_t n = __popcll(need);
 				const int ldr = __ffsll((long long)need) - 1;
-				uint32_t base = 0;
-				if ((int)lane == ldr) base = atomicAdd(&ctr->hole_cursor, n);
-				base = __shfl(base, ldr);
+				uint32_t base = wave * 64u;
+				if (!first) {
+					if ((int)lane == ldr) base = atomicAdd(&ctr->hole_cursor, n);
+					base = __shfl(base, ldr) + nwaves * 64u;
+				}
+				first = false;
+				if (nwaves * 64u >= nholes) exhausted = true; // (every hole is some wave's own)
 				if (!active) {
 					const uint32_t my = base + __popcll(need & lt);
 					if (my < nholes) {
