@@ -2418,12 +2418,44 @@ __global__ __launch_bounds__(256) void vary_kernel(const K *__restrict__ keys, u
 {
 	K o = 0, a = ~(K)0;
 	const uint64_t cnt = (n + stride - 1) / stride;
-	const uint64_t step = (uint64_t)gridDim.x * 256;
-	for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cnt; i += step) {
-		const K k = keys[i * stride];
-		o |= k;
-		a &= k;
-	}
+	const uint64_t step = (uint64_t)gridDim.x * 256, t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	if (stride == 1) { // every key: 16-byte nontemporal loads on the array's 16-byte grid, four in flight (read-only stream)
+		constexpr int VEC = 16 / (int)sizeof(K);
+		const uint64_t lead = min(n, (uint64_t)((VEC - (int)(((uintptr_t)keys / sizeof(K)) % VEC)) % VEC));
+		const uint64_t nvec = (n - lead) / VEC;
+		const u32x4 *v = reinterpret_cast<const u32x4 *>(keys + lead);
+		auto take = [&](const u32x4 &q) {
+			if constexpr (sizeof(K) == 4) {
+				o |= (K)(q.x | q.y | q.z | q.w);
+				a &= (K)(q.x & q.y & q.z & q.w);
+			} else {
+				const K k0 = (K)q.x | ((K)q.y << 32), k1 = (K)q.z | ((K)q.w << 32);
+				o |= k0 | k1;
+				a &= k0 & k1;
+			}
+		};
+		uint64_t i = t0;
+		for (; i + 3 * step < nvec; i += 4 * step) {
+			const u32x4 q0 = __builtin_nontemporal_load(v + i), q1 = __builtin_nontemporal_load(v + i + step);
+			const u32x4 q2 = __builtin_nontemporal_load(v + i + 2 * step), q3 = __builtin_nontemporal_load(v + i + 3 * step);
+			take(q0); take(q1); take(q2); take(q3);
+		}
+		for (; i < nvec; i += step) take(__builtin_nontemporal_load(v + i));
+		const uint64_t tail0 = lead + nvec * VEC; // the single keys at both ends
+		if (t0 < lead) {
+			o |= keys[t0];
+			a &= keys[t0];
+		}
+		if (tail0 + t0 < n) {
+			o |= keys[tail0 + t0];
+			a &= keys[tail0 + t0];
+		}
+	} else
+		for (uint64_t i = t0; i < cnt; i += step) {
+			const K k = keys[i * stride];
+			o |= k;
+			a &= k;
+		}
 #pragma unroll
 	for (int s = 32; s > 0; s >>= 1) {
 		o |= __shfl_xor(o, s);

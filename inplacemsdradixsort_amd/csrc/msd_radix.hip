@@ -948,18 +948,16 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	// of stage 1 go to the general LDS sort (their number is only known on the device)
 	if (!single_pass) {
 		const uint32_t nsm = nsmall_host + (HV ? ncount_host : 0u); // tuples: both lists hold leaf_count work
+		// persistent workgroups with prefetch of the next segment: as many per CU as the LDS holds
+		constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
+		const uint32_t leaf_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / C::SORT_TH, (160 * 1024) / (leaf_lds + 512)));
 		if (nsmall_host) {
-			constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
-			// persistent workgroups (one per CU fits the LDS) with prefetch of the next segment
-			// persistent workgroups: as many per CU as the LDS holds
-			const uint32_t leaf_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / C::SORT_TH, (160 * 1024) / (leaf_lds + 512)));
 			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(nsmall_host, (uint32_t)c->sm_count * leaf_per_cu)), dim3(C::SORT_TH), leaf_lds, c->stream,
 					   keys, vals, small, nsmall_host, small + nsmall_host, ctr, &ctr->leaf_ticket[0]);
 			HIPCHK(c, hipGetLastError());
 		}
-		if (HV && ncount_host) {
-			constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
-			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count)), dim3(C::SORT_TH), leaf_lds, c->stream,
+		if (HV && ncount_host) { // (tuples whose last <= 16 bits are open -- 5b after its rounds: same kernel, its own ticket)
+			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count * leaf_per_cu)), dim3(C::SORT_TH), leaf_lds, c->stream,
 					   keys, vals, small_count, ncount_host, small + nsmall_host, ctr, &ctr->leaf_ticket[1]);
 			HIPCHK(c, hipGetLastError());
 		}

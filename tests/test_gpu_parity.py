@@ -229,6 +229,24 @@ def test_unaligned_subarray(ctx, off):
     assert (out[off:] == np.sort(k[off:])).all()
 
 
+@pytest.mark.parametrize("where", ["first", "last", "vector_tail", "middle"])
+@pytest.mark.parametrize("n", [4099, 100003, (1 << 20) + 2])
+def test_bit_skip_sees_every_key(ctx, n, where):
+    """The exact OR/AND pass behind leading-bit skipping reads 16-byte vectors plus single keys at both ends: one key
+    that differs from all others in a leading bit, at the positions that are easy to miss, must still be sorted right."""
+    k = O.gen_uniform_u32(n, seed=n) & np.uint32(0xFFFF)       # 16 constant leading bits ...
+    at = {"first": 0, "last": n - 1, "vector_tail": (n // 4) * 4 - 1, "middle": n // 2 + 1}[where]
+    k[at] |= np.uint32(1 << 30)                                 # ... except in one key
+    t = dev(k)
+    ctx.sort_u32(t)
+    assert (host(t) == np.sort(k)).all()
+    k64 = (O.gen_uniform_u32(n, seed=n + 1).astype(np.uint64) & np.uint64(0xFFFFF))
+    k64[at] |= np.uint64(1 << 61)
+    t = dev(k64)
+    ctx.sort_u64(t)
+    assert (host(t) == np.sort(k64)).all()
+
+
 def test_misaligned_pointer_is_rejected(ctx):
     from inplacemsdradixsort_amd import MsdError
     t = dev(O.gen_uniform_u32(1000))

@@ -2,7 +2,7 @@
 """Time one sort of 2^logn uniform u32 keys with an experimental build of the library
 (inplacemsdradixsort_amd._build.build_variant / build_stamps) and print its phase table.
 
-    python tools/variant_run.py <library suffix, e.g. "stamps" or "v1"> [logn] [u32|zipf|u64|pairs]
+    python tools/variant_run.py <library suffix, e.g. "stamps" or "v1"> [logn] [u32|zipf|dup<k>|u64|pairs|pairs5b]
 """
 import ctypes as C
 import json
@@ -45,7 +45,7 @@ else:
     t = torch.empty(n, dtype=torch.int64, device="cuda")
     r = torch.empty(n, dtype=torch.int64, device="cuda")
     def gen(s):
-        ctx.gen_uniform_u64(t, seed=0x5EED0005 + s)
+        ctx.gen_uniform_u64(t, seed=0x5EED0005 + s, shift_right=32 if kind == "pairs5b" else 0)
         ctx.gen_iota_u64(r)
     run = lambda: ctx.sort_pairs_u64(t, r)
 times = []
