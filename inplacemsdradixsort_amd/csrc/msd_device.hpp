@@ -1473,42 +1473,69 @@ __global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArr
 	}
 }
 
-// children -> next round's parents / the small-segment lists / done
-__global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, ChildArrays ca,
+// children -> next round's parents / the small-segment lists / done.  A workgroup serves 256 >> wmax parents (wmax:
+// the round's widest digit) and takes its places in each list with ONE fetch-add per list: the list counters are single
+// words, and a fetch-add per wave on one word is what the device serialises (65536 narrow parents of a register-resident
+// round, one wave each: 0.7 ms).
+__global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, uint32_t nparents, uint32_t wmax, ChildArrays ca,
 	uint64_t small_max, uint64_t med_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
 	Segment *__restrict__ small, Segment *__restrict__ small_count, Segment *__restrict__ big, uint32_t big_cap,
 	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out, uint32_t count_n)
 {
-	const Parent pa = parents[blockIdx.x];
-	const uint32_t d = threadIdx.x;
-	if (d >= (1u << pa.width)) return;
-	const uint32_t ci = pa.child_base + d;
-	const uint64_t c = ca.count[ci];
-	if (count_out && ci < count_n) count_out[ci] = c;
-	if (c <= 1 || pa.shift == 0) return;
-	Segment s;
-	s.start = ca.start[ci];
-	s.count = c;
-	s.bits = pa.shift;
-	s.pad = 0;
-	const bool countable = pa.shift <= count_bits; // all open bits fit one counting pass
-	if (countable && c >= 64 && c <= med_max) {     // one workgroup: LDS byte counters
-		const uint32_t at = atomicAdd(&ctr->ncount, 1u);
-		if (at < small_cap) small_count[at] = s; else atomicAdd(&ctr->errors, 1u);
-	} else if (c > small_max) {
-		uint32_t at = 0xFFFFFFFFu;
-		if (big && countable && c < 0xFFFF0000ull) at = atomicAdd(&ctr->nbig, 1u);
-		if (at < big_cap)
-			big[at] = s; // no further round: counted and re-generated by the multi-workgroup counting sort
-		else
-		{
-			next_parents[atomicAdd(&ctr->next_parents, 1u)] = s;
-			atomicMax(&ctr->next_max, (uint32_t)(c < 0xFFFFFFFFull ? c : 0xFFFFFFFFull));
+	__shared__ uint32_t s_n[4], s_base[4], s_max; // lists: 0 small, 1 counting leaf, 2 big counting sort, 3 next parents
+	const uint32_t tid = threadIdx.x;
+	if (tid < 4) s_n[tid] = 0;
+	if (tid == 0) s_max = 0;
+	__syncthreads();
+	const uint32_t pi = blockIdx.x * (256u >> wmax) + (tid >> wmax), d = tid & ((1u << wmax) - 1u);
+	int which = -1;
+	uint32_t rank = 0;
+	Segment s = {};
+	if (pi < nparents) {
+		const Parent pa = parents[pi];
+		if (d < (1u << pa.width)) {
+			const uint32_t ci = pa.child_base + d;
+			const uint64_t c = ca.count[ci];
+			if (count_out && ci < count_n) count_out[ci] = c;
+			if (c > 1 && pa.shift != 0) {
+				s.start = ca.start[ci];
+				s.count = c;
+				s.bits = pa.shift;
+				s.pad = 0;
+				const bool countable = pa.shift <= count_bits; // all open bits fit one counting pass
+				if (countable && c >= 64 && c <= med_max)
+					which = 1; // one workgroup: LDS byte counters
+				else if (c > small_max)
+					which = (big && countable && c < 0xFFFF0000ull) ? 2 : 3; // no further round: the multi-workgroup counting sort
+				else
+					which = 0;
+				rank = atomicAdd(&s_n[which], 1u);
+				if (which == 3) atomicMax(&s_max, (uint32_t)(c < 0xFFFFFFFFull ? c : 0xFFFFFFFFull));
+			}
 		}
-	} else {
-		const uint32_t at = atomicAdd(&ctr->nsmall, 1u);
-		if (at < small_cap) small[at] = s; else atomicAdd(&ctr->errors, 1u);
 	}
+	__syncthreads();
+	if (tid < 4 && s_n[tid]) {
+		uint32_t *cnt = tid == 0 ? &ctr->nsmall : tid == 1 ? &ctr->ncount : tid == 2 ? &ctr->nbig : &ctr->next_parents;
+		s_base[tid] = atomicAdd(cnt, s_n[tid]);
+		if (tid == 3) atomicMax(&ctr->next_max, s_max);
+	}
+	__syncthreads();
+	if (which < 0) return;
+	uint32_t at = s_base[which] + rank;
+	if (which == 2 && at >= big_cap) { // the big list is full: another round instead
+		which = 3;
+		at = atomicAdd(&ctr->next_parents, 1u);
+		atomicMax(&ctr->next_max, (uint32_t)(s.count < 0xFFFFFFFFull ? s.count : 0xFFFFFFFFull));
+	}
+	if (which == 3)
+		next_parents[at] = s;
+	else if (which == 2)
+		big[at] = s;
+	else if (at < small_cap)
+		(which == 0 ? small : small_count)[at] = s;
+	else
+		atomicAdd(&ctr->errors, 1u);
 }
 
 } // namespace msd

@@ -596,7 +596,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					hipLaunchKernelGGL((regpart_kernel<V>), dim3(std::min<uint32_t>(np, (uint32_t)c->sm_count)), dim3(kRpTh), kRpLds, c->stream,
 							   (uint64_t *)keys, vals, (const Parent *)d_parents, np, ca, ctr);
 					phase_mark(c, "A register partition");
-					hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, (const Parent *)d_parents, ca, small_max, small_max,
+					const uint32_t wmax_rp = regpart_width(kRpCap, 64, small_max); // (the widest digit of the rule)
+					hipLaunchKernelGGL(collect_kernel, dim3((np + (256u >> wmax_rp) - 1) / (256u >> wmax_rp)), dim3(256), 0, c->stream, (const Parent *)d_parents, np, wmax_rp, ca, small_max, small_max,
 							   (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu), count_bits, d_next, small, small_count,
 							   HV ? (Segment *)nullptr : big, big_cap, ctr, (uint64_t *)nullptr, nc);
 					HIPCHK(c, hipGetLastError());
@@ -776,7 +777,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		hipLaunchKernelGGL((cleanup_kernel<K, V>), dim3(ns), dim3(256), 0, c->stream, rb.stripes, rb.parents, rb.lo_cnt,
 				   rb.lo_off, rb.lo_dst, rb.ca, (const K *)rb.lo_keys, rb.lo_vals, keys, vals);
 		hipLaunchKernelGGL((excess_kernel<K, V>), dim3(nc), dim3(64), 0, c->stream, nc, rb.ca, (const K *)rb.xkeys, rb.xvals, keys, vals);
-		hipLaunchKernelGGL(collect_kernel, dim3(np), dim3(256), 0, c->stream, rb.parents, rb.ca,
+		uint32_t wmax = 1;
+		for (size_t i = 0; i < np; ++i) wmax = std::max(wmax, rp.parents[i].width);
+		hipLaunchKernelGGL(collect_kernel, dim3((np + (256u >> wmax) - 1) / (256u >> wmax)), dim3(256), 0, c->stream, (const Parent *)rb.parents, np, wmax, rb.ca,
 				   single_pass ? ~0ull : small_max, (HV || single_pass) ? small_max : std::max<uint64_t>(small_max, kCountMedMax),
 				   small_cap, single_pass ? 0u : count_bits,
 				   rb.next_parents, small, small_count, (HV || single_pass) ? (Segment *)nullptr : big, big_cap, ctr,
