@@ -52,6 +52,7 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 	uint32_t *nexti = wtot + 9, *hi_l = wtot + 10, *crowded = wtot + 11;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 	if (blockIdx.x >= nsegs) return;
+	if (tid == 0) wtot[13] = 0; // tickets in hand (only thread 0 uses them)
 	// segment descriptors are the same in every lane: keep them in scalar registers (loaded through vector
 	// memory or LDS they would make every address a per-lane 64-bit computation)
 	auto uniform = [](Segment g) -> Segment {
@@ -109,7 +110,16 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 			if (q < kC16Cap / 4) reinterpret_cast<u32x4 *>(cw)[q] = u32x4{ zero, zero, zero, zero };
 		}
 		if (tid == 0) {
-			*nexti = atomicAdd(&ctr->count_ticket3, 1u) + gridDim.x;
+			// (tickets two at a time when there are many segments: fewer fetch-adds on the one ticket word; the pair
+			// in hand lives in LDS, wtot[12] next / wtot[13] how many)
+			if (wtot[13] == 0) {
+				const uint32_t take = nsegs > 64u * gridDim.x ? 2u : 1u;
+				wtot[12] = atomicAdd(&ctr->count_ticket3, take) + gridDim.x;
+				wtot[13] = take;
+			}
+			*nexti = wtot[12];
+			wtot[12] += 1;
+			wtot[13] -= 1;
 			*crowded = 0;
 			const uint32_t k0 = off == 0 ? rk[0] : off == 1 ? rk[1] : off == 2 ? rk[2] : rk[3]; // first key
 			*hi_l = k0 & 0xFFFF0000u; // common prefix of the whole segment

@@ -1893,7 +1893,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 	K *xk = reinterpret_cast<K *>(smem);
 	uint64_t *xv = reinterpret_cast<uint64_t *>(smem + (size_t)CAP * sizeof(K));
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)CAP * (sizeof(K) + (HV ? 8 : 0))); // 2 x 16-bit counters per word
-	uint32_t *wtot = cw + ((size_t)1 << LB) / 2; // 16 wave totals, [16] flag, [17] next ticket
+	uint32_t *wtot = cw + ((size_t)1 << LB) / 2; // 16 wave totals, [16] flag, [17] next ticket, [18..19] tickets in hand
 	K *s_or = reinterpret_cast<K *>(wtot + 32);              // [2] OR / AND of the keys
 	if (blockIdx.x >= nsegs) return;
 	const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1912,51 +1912,72 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 		}
 	};
 	prefetch(sg);
+	if (tid == 0) wtot[19] = 0; // tickets in hand (only thread 0 uses them)
 	MSD_STAMP_DECL(3);
 	MSD_STAMP_START();
 	for (;;) {
 		MSD_STAMP(9); // loop
 		MSD_STAMP_TICK(11);
 		const uint32_t n = (uint32_t)sg.count;
+		// (uniform) all open bits fit the counters: which of them vary does not matter, the OR/AND reduction and its
+		// barrier are skipped (tuples whose rounds left 13 bits: a fifth of the segment's time)
+#ifndef MSD_LEAF_NARROW // (0: experiments)
+#define MSD_LEAF_NARROW 1
+#endif
+		const bool narrow = MSD_LEAF_NARROW && sg.bits <= (uint32_t)LB;
 		K k_or = 0, k_and = ~(K)0;
+		if (!narrow) {
 #pragma unroll
-		for (int i = 0; i < KPT; ++i) {
-			if ((uint32_t)(i * TH) + tid < n) {
-				k_or |= kr[i];
-				k_and &= kr[i];
+			for (int i = 0; i < KPT; ++i) {
+				if ((uint32_t)(i * TH) + tid < n) {
+					k_or |= kr[i];
+					k_and &= kr[i];
+				}
 			}
 		}
 		if (tid == 0) {
 			s_or[0] = 0;
 			s_or[1] = ~(K)0;
 			wtot[16] = 0;
-			wtot[17] = atomicAdd(ticket, 1u) + gridDim.x;
+			// (tickets four at a time when there are many segments: 2^19 leaves of 2^11 tuples finish at 75 per
+			// microsecond, about what a single word takes in fetch-adds)
+			// (kept in LDS, [18] next / [19] how many: two more live registers would spill)
+			if (wtot[19] == 0) {
+				const uint32_t take = nsegs > 64u * gridDim.x ? 4u : 1u;
+				wtot[18] = atomicAdd(ticket, take) + gridDim.x;
+				wtot[19] = take;
+			}
+			wtot[17] = wtot[18];
+			wtot[18] += 1;
+			wtot[19] -= 1;
 		}
 		for (uint32_t j = tid; j < ((uint32_t)1 << LB) / 2; j += TH) cw[j] = 0;
 		MSD_STAMP(0); // wait for the keys + OR/AND + clear
 		__syncthreads();
+		if (!narrow) {
 #pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			k_or |= __shfl_xor(k_or, o);
-			k_and &= __shfl_xor(k_and, o);
-		}
-		if (lane == 0) {
-			if constexpr (sizeof(K) == 4) {
-				atomicOr(reinterpret_cast<unsigned int *>(&s_or[0]), (unsigned int)k_or);
-				atomicAnd(reinterpret_cast<unsigned int *>(&s_or[1]), (unsigned int)k_and);
-			} else {
-				atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
-				atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
+			for (int o = 32; o > 0; o >>= 1) {
+				k_or |= __shfl_xor(k_or, o);
+				k_and &= __shfl_xor(k_and, o);
 			}
+			if (lane == 0) {
+				if constexpr (sizeof(K) == 4) {
+					atomicOr(reinterpret_cast<unsigned int *>(&s_or[0]), (unsigned int)k_or);
+					atomicAnd(reinterpret_cast<unsigned int *>(&s_or[1]), (unsigned int)k_and);
+				} else {
+					atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
+					atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
+				}
+			}
+			__syncthreads();
 		}
-		__syncthreads();
 		MSD_STAMP(1); // B + merge + B
 		const uint32_t nxt = wtot[17];
 		// the next segment's descriptor travels during the counting phases (loaded where its elements are prefetched,
 		// its whole memory latency would sit in front of that prefetch)
 		const Segment nraw = segs[nxt < nsegs ? nxt : blockIdx.x];
 		const K openmask = sg.bits >= sizeof(K) * 8 ? ~(K)0 : (((K)1 << sg.bits) - 1);
-		const K vopen = (s_or[0] ^ s_or[1]) & openmask;
+		const K vopen = narrow ? openmask : (s_or[0] ^ s_or[1]) & openmask;
 		Segment nsg = sg;
 		bool fetched = false;
 		if (vopen != 0) { // (uniform) otherwise constant on the open bits: already sorted
