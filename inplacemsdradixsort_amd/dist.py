@@ -16,6 +16,8 @@ ranges per node (numa_dest, src/msb_64.c:1596-1607), blocks balanced across node
      log2(G) bits, which are passed on as ``end_bit`` (the reference passes bits=58 after
      its 6-bit split, src/msb_64.c:2242).
 
+u64 keys and (u64 key, u64 rid) tuples -- what the reference's ``sort()`` takes, one pair of arrays per memory node --
+shard the same way (``sort_sharded_u64``, ``sort_sharded_pairs_u64``).
 ``engine`` is an :class:`inplacemsdradixsort_amd.MsdContext`; the CPU gloo tests pass a
 stand-in with the same methods to exercise the exchange logic without a GPU.
 The receive buffer needs slack over n/G under skew (the reference's ``fudge``).
@@ -109,6 +111,47 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None):
     dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
     engine.sort_u32(out, end_bit=32 - lg)
     return out
+
+
+def sort_sharded_u64(engine, keys, recv, dist, world: int, group=None):
+    """:func:`sort_sharded_u32` for u64 keys (int64 tensors holding the bit patterns): top 8 bits, one all-to-all,
+    local sort with ``end_bit = 64 - log2(world)``."""
+    lg = _log2(world)
+    if world == 1:
+        engine.sort_u64(keys)
+        return keys
+    counts = engine.partition(keys, 56, 8)
+    send = counts.view(world, 256 // world).sum(dim=1)
+    send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
+    out = recv[:int(sum(got_l))]
+    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    engine.sort_u64(out, end_bit=64 - lg)
+    return out
+
+
+def sort_sharded_pairs_u64(engine, keys, rids, recv_keys, recv_rids, dist, world: int, group=None):
+    """The reference's own job across devices: (u64 key, u64 rid) tuples held in one (keys, rids) pair of arrays per
+    memory node (``sort(keys, rids, size, threads, numa, ...)``, src/msb_64.c:2261; contiguous key ranges per node
+    :1596-1607, local sorting :2200-2255) -- here one pair per GPU.  One in-place pass on the top 8 key bits moves keys
+    and rids together, the counts are exchanged once, keys and rids travel in two all-to-alls with the same splits,
+    and every rank sorts the tuples it received on the remaining bits (``end_bit = 64 - log2(world)``, the
+    reference's ``bits`` after its split, :2242).  Returns (keys, rids) views of the receive buffers; rank r's keys
+    precede rank r+1's; like the reference's, the sort is unstable."""
+    lg = _log2(world)
+    if world == 1:
+        engine.sort_pairs_u64(keys, rids)
+        return keys, rids
+    if recv_keys.numel() != recv_rids.numel():
+        raise ValueError("receive buffers for keys and rids differ in length")
+    counts = engine.partition(keys, 56, 8, rids=rids)
+    send = counts.view(world, 256 // world).sum(dim=1)
+    send_l, got_l = exchange_counts(dist, send, recv_keys.numel(), world, group)
+    m = int(sum(got_l))
+    out_k, out_r = recv_keys[:m], recv_rids[:m]
+    dist.all_to_all_single(out_k, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    dist.all_to_all_single(out_r, rids, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    engine.sort_pairs_u64(out_k, out_r, end_bit=64 - lg)
+    return out_k, out_r
 
 
 class ShardedSorter:

@@ -18,12 +18,29 @@ sys.path.insert(0, ROOT)
 class NumpyEngine:
     """Stand-in with MsdContext's partition / sort_u32 semantics (tests only)."""
 
-    def partition(self, keys, shift, radix_bits):
-        a = keys.numpy().view(np.uint32)
-        d = (a >> np.uint32(shift)) & np.uint32((1 << radix_bits) - 1)
+    def partition(self, keys, shift, radix_bits, rids=None):
+        a = keys.numpy().view(np.uint32 if keys.element_size() == 4 else np.uint64)
+        d = ((a >> a.dtype.type(shift)) & a.dtype.type((1 << radix_bits) - 1)).astype(np.int64)
         order = np.argsort(d, kind="stable")
         a[:] = a[order]
+        if rids is not None:
+            r = rids.numpy()
+            r[:] = r[order]
         return torch.from_numpy(np.bincount(d, minlength=1 << radix_bits).astype(np.int64))
+
+    def sort_u64(self, keys, end_bit=64):
+        a = keys.numpy().view(np.uint64)
+        if a.size and end_bit < 64:
+            assert int((a >> np.uint64(end_bit)).min()) == int((a >> np.uint64(end_bit)).max())
+        a.sort()
+
+    def sort_pairs_u64(self, keys, rids, end_bit=64):
+        a, r = keys.numpy().view(np.uint64), rids.numpy()
+        if a.size and end_bit < 64:
+            assert int((a >> np.uint64(end_bit)).min()) == int((a >> np.uint64(end_bit)).max())
+        order = np.argsort(a, kind="stable")
+        a[:] = a[order]
+        r[:] = r[order]
 
     def sort_u32(self, keys, end_bit=32):
         a = keys.numpy().view(np.uint32)
@@ -219,3 +236,52 @@ def test_splitters_follow_the_reference_duplicate_rule():
     L.extract_delimiters.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
     L.extract_delimiters(s.ctypes.data_as(C.POINTER(C.c_uint64)), s.size, delim.ctypes.data_as(C.POINTER(C.c_uint64)))
     assert splitters_equi_depth(s, parts) == delim[:parts - 1].tolist()
+
+
+def _wide_worker(rank, world, port, n, pairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inplacemsdradixsort_amd.dist import sort_sharded_pairs_u64, sort_sharded_u64
+    from oracle import oracle as O
+    k = O.gen_uniform_u64(n, first=rank * n)
+    keys = torch.from_numpy(k.view(np.int64).copy())
+    recv_k = torch.empty(2 * n, dtype=torch.int64)
+    if pairs:
+        rids = torch.from_numpy((k ^ np.uint64(0x5A5A5A5A5A5A5A5A)).view(np.int64).copy())   # rid = f(key): the pairing can be checked
+        out_k, out_r = sort_sharded_pairs_u64(NumpyEngine(), keys, rids, recv_k, torch.empty(2 * n, dtype=torch.int64), dist, world)
+        q.put((rank, out_k.numpy().view(np.uint64).copy(), out_r.numpy().view(np.uint64).copy()))
+    else:
+        out = sort_sharded_u64(NumpyEngine(), keys, recv_k, dist, world)
+        q.put((rank, out.numpy().view(np.uint64).copy(), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pairs", [(2, False), (4, True), (8, True)])
+def test_sharded_u64_and_tuple_sort_over_gloo(world, pairs):
+    """u64 keys and (u64 key, u64 rid) tuples -- the reference's sort() with one pair of arrays per memory node,
+    src/msb_64.c:2261 -- across ranks: global order, every rid still with its key, rank r owns top bits == r."""
+    n = 15000 if world < 8 else 5000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, n, pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, k, v = q.get(timeout=120)
+        res[r] = (k, v)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    allk = np.concatenate([O.gen_uniform_u64(n, first=r * n) for r in range(world)])
+    got = np.concatenate([res[r][0] for r in range(world)])
+    assert (got == np.sort(allk)).all()
+    lg = world.bit_length() - 1
+    for r in range(world):
+        assert ((res[r][0] >> np.uint64(64 - lg)) == r).all()
+        if pairs:
+            assert (res[r][1] == (res[r][0] ^ np.uint64(0x5A5A5A5A5A5A5A5A))).all()

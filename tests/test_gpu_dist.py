@@ -180,3 +180,55 @@ def test_sampled_splitter_sort_real_engine(world, kind, n):
             assert r[7] > prev_hi                                      # ranges (delim[p-1], delim[p]] do not share a value
             prev_hi = r[8]
     assert max(r[1] for r in res) < 1.35 * n      # balanced although 75 % of the keys share the top byte
+
+
+def _pairs_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inplacemsdradixsort_amd import MsdContext
+    from inplacemsdradixsort_amd.dist import sort_sharded_pairs_u64
+    ctx = MsdContext(0)
+    keys = torch.empty(n, dtype=torch.int64, device="cuda:0")
+    ctx.gen_uniform_u64(keys, first=rank * n)
+    rids = keys.clone()                     # the reference's own check convention: rid == key (src/msb_64.c:2461)
+    v0, s0, x0 = ctx.check(keys)
+    rk = torch.empty(2 * n, dtype=torch.int64, device="cuda:0")
+    rr = torch.empty(2 * n, dtype=torch.int64, device="cuda:0")
+    out_k, out_r = sort_sharded_pairs_u64(ctx, keys, rids, rk, rr, GlooViaCpu, world)
+    v, s, x = ctx.check(out_k, out_r)       # order + key == rid
+    M = (1 << 64) - 1
+    lo = int(out_k[0].item()) & M if out_k.numel() else -1
+    hi = int(out_k[-1].item()) & M if out_k.numel() else -1
+    q.put((rank, out_k.numel(), v, s0, x0, s, x, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+@pytest.mark.parametrize("world,n", [(2, 1 << 21), (4, 1 << 19)])
+def test_sharded_tuple_sort_real_engine(world, n):
+    """The reference's sort() across devices: (u64 key, u64 rid) tuples, one (keys, rids) pair per rank; sorted per
+    rank, key == rid everywhere, key sum and xor preserved, rank r owns the keys whose top bits are r."""
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_pairs_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sum(r[1] for r in res) == n * world and all(r[2] == 0 for r in res)
+    M = 1 << 64
+    assert sum(r[3] for r in res) % M == sum(r[5] for r in res) % M
+    x_in = x_out = 0
+    for r in res:
+        x_in ^= r[4]
+        x_out ^= r[6]
+    assert x_in == x_out
+    lg = world.bit_length() - 1
+    for r in res:
+        if r[1]:
+            assert (r[7] >> (64 - lg)) == r[0] and (r[8] >> (64 - lg)) == r[0]

@@ -73,7 +73,7 @@ def test_sort_u32_mid_sizes_equal_oracle(ctx, n, kind):
     assert (host(t) == O.sort_u32(k)).all()
 
 
-@pytest.mark.parametrize("kind", ["lowbits12", "range16", "heavy", "zipf", "twovalues"])
+@pytest.mark.parametrize("kind", ["lowbits12", "range16", "heavy", "zipf", "twovalues", "tenpercent", "fourvalues"])
 @pytest.mark.parametrize("n", [30000, (1 << 20) + 7, 1 << 23])
 def test_big_counting_sort_paths(ctx, n, kind):
     """Segments with <= 16 open bits that exceed the LDS leaf: multi-workgroup counting sort
@@ -88,6 +88,11 @@ def test_big_counting_sort_paths(ctx, n, kind):
         k[rng.random(n) < 0.5] = 777
     elif kind == "zipf":
         k = O.gen_zipf_u32(n, seed=n)
+    elif kind == "tenpercent":  # too few lanes of a wave share the value for the per-wave register count, enough keys for
+        k = rng.integers(0, 1 << 16, n, dtype=np.uint32)  # its packed 16-bit LDS counter to hand over to the histogram in HBM
+        k[rng.random(n) < 0.1] = 4242
+    elif kind == "fourvalues":  # 40 / 30 / 20 / 10 %: values counted in registers next to values counted in LDS
+        k = rng.choice(np.array([3, 70000 & 0xFFFF, 65535, 12], dtype=np.uint32), n, p=[0.4, 0.3, 0.2, 0.1]).astype(np.uint32)
     else:
         k = np.where(rng.random(n) < 0.3, np.uint32(5), np.uint32(0xFFFF0005)).astype(np.uint32)
     t = dev(k)
