@@ -829,6 +829,7 @@ struct ChildArrays {
 	uint32_t *nev;    // blocks of this child's list parked in the side store (each opens a chain start)
 	uint32_t *xfirst; // first side-store block of those
 	uint32_t *hot_cur; // kHotMax x kHotShards claim cursors (one 128-byte line each) of the longest lists
+	u32x4 *lmeta;     // per list, for the block permutation: first entry, length, chain-continuing entries, rotation -- one load
 };
 // A list of at least kHotLen entries is claimed from kHotShards cursors instead of one: on skewed inputs half of all
 // claims go to ONE list (Zipf keys: the bucket of the small keys), and a single device-scope fetch-add word saturates
@@ -1204,6 +1205,15 @@ __global__ __launch_bounds__(256) void evict_kernel(uint32_t nchildren, ChildArr
 	}
 }
 
+// What a chain step needs to know about a list, in one 16-byte load (five separate arrays cost the step two more
+// dependent round trips).
+__global__ __launch_bounds__(256) void list_pack_kernel(uint32_t nchildren, ChildArrays ca)
+{
+	const uint32_t ci = blockIdx.x * 256 + threadIdx.x;
+	if (ci >= nchildren) return;
+	ca.lmeta[ci] = u32x4{ (uint32_t)ca.list_base[ci], (uint32_t)ca.list_len[ci], ca.n_int[ci], ca.rot[ci] };
+}
+
 // ------------------------------------------------------ B: block permutation
 
 // Every lane runs one chain: own a hole -> claim the next misplaced block of the
@@ -1229,9 +1239,12 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 	constexpr int NI = 64 / BPI;      // instructions to move 64 blocks (16)
 	constexpr int GROUPS = 4;         // shared claims are formed for the 4 most common buckets
 	const uint32_t lane = lane_id();
-	const uint64_t lt = (1ull << lane) - 1ull;
 	const uint32_t nholes = ctr->nholes;
 	uint32_t hole = 0, owner = 0;
+	// the list of `owner`: {first entry, length, chain-continuing entries, rotation} and its flags -- loaded when the
+	// lane learns its next owner, i.e. while the blocks of the current step move
+	u32x4 om = { 0u, 0u, 0u, 0u };
+	uint32_t ofl = 0;
 	bool active = false, exhausted = false;
 	uint32_t steps = 0;
 	// claims from a hot list: which of its shards this lane tries next (first choice by workgroup and wave, so that the
@@ -1244,7 +1257,10 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 	// claims at the rate a single word takes them).  The cursor hands out what lies behind those.
 	const uint32_t nwaves = gridDim.x * (blockDim.x >> 6), wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	bool first = true;
+	MSD_STAMP_DECL(7);
+	MSD_STAMP_START();
 	for (;;) {
+		MSD_STAMP_TICK(11);
 		// ---- lanes without a hole fetch the next chain start
 		if (!exhausted) {
 			const uint64_t need = __ballot(!active);
@@ -1259,11 +1275,13 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 				first = false;
 				if (nwaves * 64u >= nholes) exhausted = true; // (every hole is some wave's own)
 				if (!active) {
-					const uint32_t my = base + __popcll(need & lt);
+					const uint32_t my = base + popc_below_lane(need);
 					if (my < nholes) {
 						const ListEntry e = holes[my];
 						hole = e.slot;
 						owner = e.owner;
+						om = ca.lmeta[owner];
+						ofl = ca.flags[owner];
 						active = true;
 					}
 				}
@@ -1272,13 +1290,14 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 		}
 		const uint64_t act = __ballot(active);
 		if (!act) break;
+		MSD_STAMP(0); // chain starts
 
 		// ---- claim one source block per active lane; lanes with equal owner (and shard) share a fetch-add.
 		// A hot list's chain-continuing entries [0, n_int) are split over kHotShards cursors; its chain-ending entries
 		// keep the list's own cursor and are handed out only to a lane that has found every shard used up -- a chain
 		// may only end where no chain-continuing entry of the list is left (otherwise the
 		// remaining entries can form cycles no chain enters).
-		const uint32_t fl = active ? ca.flags[owner] : 0u;
+		const uint32_t fl = active ? ofl : 0u;
 		const uint32_t hot = fl >> 8;                                  // hot id + 1, or 0
 		const uint32_t shard = !hot ? 0u : tries < kHotShards ? (shard0 + tries) % kHotShards : kHotShards; // kHotShards: the ending entries
 		const uint32_t ckey = owner * 16u + shard;                     // (owner < 2^28)
@@ -1291,26 +1310,29 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 				const int l = __ffsll((long long)rem) - 1;
 				const uint32_t o = __shfl(ckey, l);
 				const uint64_t same = __ballot(active && ckey == o) & rem;
-				if ((same >> lane) & 1ull) {
+				if (lane_bit(same)) {
 					my_ldr = l;
-					my_rank = __popcll(same & lt);
+					my_rank = popc_below_lane(same);
 					my_cnt = __popcll(same);
 				}
 				rem &= ~same;
 			}
 		}
+		MSD_STAMP(1); // owner flags + grouping
 		uint32_t idx = 0;
 		if (active && my_ldr == (int)lane)
 			idx = atomicAdd(hot && shard < kHotShards ? &ca.hot_cur[(size_t)((hot - 1) * kHotShards + shard) * kRposStride]
 								  : &ca.rpos[(size_t)owner * kRposStride], my_cnt);
 		idx = __shfl(idx, my_ldr) + my_rank;
 
+		MSD_STAMP(2); // claim
 		uint32_t src = 0, src_owner = kNoOwner;
 		bool last = false, retry = false;
+		u32x4 nom = om;
+		uint32_t nfl = ofl;
 		if (active) {
-			const uint32_t len = (uint32_t)ca.list_len[owner];
+			const uint32_t len = om.y, nint = om.z;
 			if (hot) {
-				const uint32_t nint = ca.n_int[owner];
 				if (shard < kHotShards) { // shard `shard` holds the chain-continuing entries [n_int * shard / S, n_int * (shard + 1) / S)
 					const uint32_t sb = (uint32_t)((uint64_t)nint * shard / kHotShards), se = (uint32_t)((uint64_t)nint * (shard + 1) / kHotShards);
 					if (idx < se - sb)
@@ -1328,24 +1350,30 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 				active = false;
 			} else {
 				tries = 0;
-				const uint32_t ni = ca.n_int[owner];
-				last = idx >= ni;
+				last = idx >= nint;
 				uint32_t at = idx;
 				if (!last) { // chain-continuing entries: rotated order
-					at += ca.rot[owner];
-					if (at >= ni) at -= ni;
+					at += om.w;
+					if (at >= nint) at -= nint;
 				}
-				const ListEntry e = list[(uint32_t)ca.list_base[owner] + at];
+				const ListEntry e = list[om.x + at];
 				src = e.slot;
 				src_owner = e.owner;
 				if (!slot_ok(src) || !slot_ok(hole)) {
 					atomicAdd(&ctr->errors, 1u);
 					active = false;
+				} else if (!last) { // the next step's list: on its way while this step's blocks move
+					nom = ca.lmeta[src_owner];
+					nfl = ca.flags[src_owner];
 				}
 			}
 		}
 		const uint64_t mv = __ballot(active && !retry);
 		++steps;
+		MSD_STAMP(3); // list geometry + entry
+#ifdef MSD_STAMPS
+		if constexpr (kStampThis) st_acc[10] += __popcll(mv);
+#endif
 
 		// ---- move the claimed blocks: lane group g of instruction i serves chain i*BPI+g.
 		// Loads are unconditional (idle chains read slot 0) so that the 16 vectors stay in registers.
@@ -1377,9 +1405,13 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 			else {
 				hole = src;
 				owner = src_owner;
+				om = nom;
+				ofl = nfl;
 			}
 		}
+		MSD_STAMP(4); // block loads + stores
 	}
+	MSD_STAMP_FLUSH(4);
 	if (lane == 0 && steps) atomicAdd(&ctr->chain_steps, steps);
 }
 

@@ -46,6 +46,7 @@ struct msd_ctx {
 	std::vector<std::pair<std::string, double>> phase_us;
 	std::vector<std::pair<std::string, uint64_t>> stats;
 	int sm_count = 256;
+	int chains_per_cu[3] = { 4, 4, 2 }; // resident chains_kernel workgroups per CU: u32 keys, u64 keys, tuples (measured at msd_create)
 	// direct block placement in the first round: 0 off, 1 when the sampled
 	// children are about equally big, 2 whenever the geometry allows (tests)
 	int direct_mode = 1;
@@ -344,6 +345,7 @@ static void carve_round(Bump &b, const RoundPlan &rp, uint64_t small_max, RoundB
 	rb.ca.nev = b.take<uint32_t>(nc);
 	rb.ca.xfirst = b.take<uint32_t>(nc);
 	rb.ca.hot_cur = b.take<uint32_t>((size_t)kHotMax * kHotShards * kRposStride);
+	rb.ca.lmeta = b.take<u32x4>(nc);
 	rb.list = b.take<ListEntry>(rp.nslots + 1);
 	// holes: tail slots (< kP + 2 per stripe) + one eviction + one excess per child
 	// + the eviction pool: what it takes to reach kMinChains chains (shared out in proportion to the list
@@ -765,7 +767,13 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 		// ---- B: block permutation
 		{
-			const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, std::max<uint64_t>(1, (rp.nslots + 255) / 256));
+			// Exactly the workgroups the chip holds at once: a wave's first 64 chain starts are its own by position and the
+			// rest come from the cursor as its chains end, so every hole is in the hands of a running wave from the start.
+			// (Twice as many workgroups: those of the second half whose share held holes started when the first finished
+			// -- 2^30 Zipf keys: 1.3 ms where a wave's own work takes 0.7.)
+			const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * c->chains_per_cu[HV ? 2 : sizeof(K) == 8 ? 1 : 0],
+									 std::max<uint64_t>(1, (rp.nslots + 255) / 256));
+			hipLaunchKernelGGL(list_pack_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca);
 			hipLaunchKernelGGL((chains_kernel<K, V>), dim3(grid), dim3(256), 0, c->stream, rb.ca, rb.list, rb.holes, ctr,
 					   keys, vals, (K *)rb.xkeys, rb.xvals, (uint32_t)(n / B), (uint32_t)(4 * nc + kMinChains));
 			hipLaunchKernelGGL(chains_verify_kernel, dim3((nc + 255) / 256), dim3(256), 0, c->stream, nc, rb.ca, ctr);
@@ -981,6 +989,11 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 {
+	{ // the block permutation is launched with exactly the workgroups the chip holds at once (see chains_grid)
+		int per_cu = 0;
+		HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chains_kernel<K, V>, 256, 0));
+		c->chains_per_cu[has_val<V>::value ? 2 : sizeof(K) == 8 ? 1 : 0] = std::max(1, per_cu);
+	}
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_kernel<K, V, false>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)ClassifyLds<K, V>::bytes));
 	if constexpr (kHasRange<K, V>)

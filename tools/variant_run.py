@@ -77,6 +77,8 @@ if hasattr(L, "msd_debug_stamps"):
         NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
     if name.startswith("sstamps"):  # classify_kernel (streaming) sections
         NAMES = ["ranks", "B1", "bookkeeping", "B2", "scatter", "B3", "drain", "refill issue", "flush", "loop", "-", "tiles"]
+    if name.startswith("chstamps"):  # chains_kernel sections (per wave step); 10: blocks moved per step
+        NAMES = ["chain starts", "owner flags+grouping", "claim", "list geometry+entry", "block loads+stores", "-", "-", "-", "-", "-", "blocks moved", "steps"]
     if name.startswith("wstamps"):  # bigcount_write_kernel sections
         NAMES = ["look-ups", "tile inside one run", "2 barriers", "runs of the tile", "B+long runs", "B", "LDS->array", "-", "-", "-", "fast tiles", "tiles"]
     if name.startswith("hstamps"):  # bigcount_hist_kernel sections
