@@ -371,7 +371,10 @@ def main():
                 algo = n * per_elem
             avg_us = ph[dom] / launches
             ach = algo / (avg_us * 1e-6) / 1e9
-            traffic = (pmc or {}).get(name, {}).get("hbm_bytes_per_launch")
+            rec = (pmc or {}).get(name)
+            if rec is None and pmc:  # extra template arguments in the profiler's name: classify_kernel<u32, false>
+                rec = next((v for k, v in pmc.items() if k.startswith(name[:-1] + ",")), None)
+            traffic = (rec or {}).get("hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                         # the PMC bytes are a committed measurement of the same kernel and workload (separate rocprofv3
