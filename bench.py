@@ -255,11 +255,15 @@ def main():
     # N > 1: receive buffers with 12.5 % slack (the reference's fudge); the exchange of step s runs (RCCL stream, xGMI)
     # while step s-1 is sorted locally -- inplacemsdradixsort_amd.dist.ShardedSorter.  One buffer per step (up to 8), so
     # that the outputs of the last steps are still there when the clock has stopped and can all be verified.
+    # The arrived runs (per source rank, that source's buckets of this rank's range) are gathered bucket-major into a
+    # work buffer and sorted there as 256 / N segments on the remaining 24 bits: the local sort does not repeat the
+    # top-digit pass.  Two receive buffers (one being filled, one being gathered from), one work buffer per step kept.
     nrecv = max(2, min(W + K, 8))
-    recv = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(nrecv)] if N > 1 else None
+    recv = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(2)] if N > 1 else None
+    work = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(nrecv)] if N > 1 else None
 
     from inplacemsdradixsort_amd.dist import ShardedSorter
-    sorter = ShardedSorter(ctx, dist, N, recv) if N > 1 else None
+    sorter = ShardedSorter(ctx, dist, N, recv, work_bufs=work) if N > 1 else None
 
     def run_steps(lo, hi):
         if N == 1:
@@ -416,7 +420,7 @@ def main():
         "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic" + (" (REHEARSAL: gloo via host memory, all ranks on one GPU)" if rehearsal else ""),
         "config": {"workload": f"2^{args.logn} {cfg['title']} per GPU, in-place MSD radix sort, 8-bit digits"
-                               + (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local sort)" if N > 1 else ""),
+                               + (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local sort; the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N > 1 else ""),
                    "config_id": args.config, "elements_per_gpu": n, "passes": cfg["passes_note"],
                    "verified": bool(verified), "steps_verified": steps_verified,
                    "workspace_bytes": ctx.workspace_bytes},

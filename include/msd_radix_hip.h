@@ -101,6 +101,26 @@ int msd_partition_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n,
 int msd_partition_pairs_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n,
 			    unsigned shift, unsigned radix_bits, uint64_t *d_count);
 
+/* ---- segmented sort and run gather: a rank of the multi-GPU sort after its exchange ----
+ * The reference's nodes sort their key ranges locally after the blocks have been balanced and swapped
+ * (src/msb_64.c:2200-2255: every node's buckets are whole, local_radixsort takes the remaining `bits`, :2242).
+ * Here a rank receives, from every source rank, that source's buckets of the rank's key range in order (one
+ * all-to-all); msd_gather_runs_* copies all those runs in ONE launch to a second buffer where every bucket is
+ * contiguous (run i: `len[i]` elements from d_src + src_off[i] to d_dst + dst_off[i]; the three arrays are HOST
+ * arrays; runs must not overlap in d_dst; d_dst and d_src must not overlap), and msd_sort_*_segments sorts
+ * nseg independent segments [seg_off[i], seg_off[i+1]) (HOST array of nseg + 1 ascending element offsets,
+ * seg_off[nseg] <= n) on their low `end_bit` bits -- all keys of a segment must agree above them -- in one
+ * call: the segments are the parents of the first round, so the local sort starts where the top-digit pass
+ * before the exchange left off instead of repeating it. */
+int msd_sort_u32_segments(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, const uint64_t *seg_off, uint32_t nseg, int end_bit);
+int msd_sort_u64_segments(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, const uint64_t *seg_off, uint32_t nseg, int end_bit);
+int msd_sort_pairs_u64_segments(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n,
+				const uint64_t *seg_off, uint32_t nseg, int end_bit);
+int msd_gather_runs_u32(msd_ctx *ctx, uint32_t *d_dst, const uint32_t *d_src, const uint64_t *src_off,
+			const uint64_t *dst_off, const uint64_t *len, uint32_t nruns);
+int msd_gather_runs_u64(msd_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, const uint64_t *src_off,
+			const uint64_t *dst_off, const uint64_t *len, uint32_t nruns);
+
 /* ---- splitter service: sample -> sort (msd_sort_u32) -> delimiters -> range partition ----
  * The reference's front end for skewed keys (src/msb_64.c:1511-1564): a random sample of the
  * UNSORTED data (:1511-1521, index = mulhi(rand64, n); here a counter-based generator, seed + i),

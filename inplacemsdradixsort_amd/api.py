@@ -114,6 +114,35 @@ class MsdContext:
             self._ok(self._L.msd_partition_u64(self._h, self._ptr(keys, 8), keys.numel(), shift, radix_bits, C.c_void_p(cnt.data_ptr())))
         return cnt
 
+    # ---- a rank of the multi-GPU sort after its exchange (reference: local sorting of whole key ranges, src/msb_64.c:2200-2255)
+    @staticmethod
+    def _u64arr(xs):
+        return (C.c_uint64 * len(xs))(*[int(x) for x in xs])
+
+    def sort_segments(self, keys, seg_off, end_bit: int, rids=None) -> None:
+        """Sorts the independent segments [seg_off[i], seg_off[i+1]) on their low ``end_bit`` bits in one call
+        (``seg_off``: nseg + 1 ascending element offsets on the host)."""
+        nseg = len(seg_off) - 1
+        if nseg <= 0:
+            return
+        off = self._u64arr(seg_off)
+        if rids is not None:
+            self._ok(self._L.msd_sort_pairs_u64_segments(self._h, self._ptr(keys, 8), self._ptr(rids, 8), keys.numel(), off, nseg, end_bit))
+        elif keys.element_size() == 4:
+            self._ok(self._L.msd_sort_u32_segments(self._h, self._ptr(keys, 4), keys.numel(), off, nseg, end_bit))
+        else:
+            self._ok(self._L.msd_sort_u64_segments(self._h, self._ptr(keys, 8), keys.numel(), off, nseg, end_bit))
+
+    def gather_runs(self, dst, src, src_off, dst_off, lens) -> None:
+        """Copies run i (``lens[i]`` elements) from ``src[src_off[i]:]`` to ``dst[dst_off[i]:]``, all runs in one launch."""
+        if not (len(src_off) == len(dst_off) == len(lens)):
+            raise MsdError("gather_runs: the three lists differ in length")
+        if dst.element_size() != src.element_size():
+            raise MsdError("gather_runs: element sizes differ")
+        f = self._L.msd_gather_runs_u32 if src.element_size() == 4 else self._L.msd_gather_runs_u64
+        self._ok(f(self._h, self._ptr(dst, dst.element_size()), self._ptr(src, src.element_size()),
+                   self._u64arr(src_off), self._u64arr(dst_off), self._u64arr(lens), len(lens)))
+
     # ---- splitter service (reference: src/msb_64.c:1511-1521, :1304-1322, :188-204)
     def sample_u32(self, keys, m: int, seed: int = 0x5EED0007):
         """m keys drawn from the (unsorted) tensor at pseudo-random positions mulhi(splitmix64(seed + i), n)."""

@@ -2488,6 +2488,77 @@ __global__ __launch_bounds__(kScanTh) void scan_lookback_kernel(const uint64_t *
 	}
 }
 
+// ------------------------------------------------- run gather (multi-GPU: source-major -> bucket-major)
+
+// After the all-to-all a rank holds, per source rank, that source's buckets in order; the local sort wants every bucket
+// contiguous.  One launch copies all runs (nruns of them, any lengths) to their places in a second buffer.
+struct GatherRun {
+	uint64_t src, dst, len;  // element offsets and length
+	uint32_t first_chunk;    // index of the run's first chunk of kGatherChunk elements
+	uint32_t pad;
+};
+#ifndef MSD_GATHER_CHUNK
+#define MSD_GATHER_CHUNK 2048
+#endif
+constexpr uint32_t kGatherChunk = MSD_GATHER_CHUNK;
+
+template <typename K>
+__global__ __launch_bounds__(256) void gather_runs_kernel(K *__restrict__ dst, const K *__restrict__ src,
+	const GatherRun *__restrict__ runs, uint32_t nruns, uint32_t nchunks)
+{
+	constexpr int VEC = 16 / (int)sizeof(K);
+	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+		uint32_t lo = 0, hi = nruns; // runs[lo].first_chunk <= c < runs[hi].first_chunk
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (runs[mid].first_chunk <= c) lo = mid; else hi = mid;
+		}
+		const GatherRun r = runs[lo];
+		const uint64_t off = (uint64_t)(c - r.first_chunk) * kGatherChunk;
+		const uint32_t len = (uint32_t)(r.len - off < (uint64_t)kGatherChunk ? r.len - off : (uint64_t)kGatherChunk);
+		K *d = dst + r.dst + off;
+		const K *s = src + r.src + off;
+		// 16-byte stores on the destination's grid
+		const uint32_t lead = min(len, (uint32_t)((VEC - (int)(((uintptr_t)d / sizeof(K)) % VEC)) % VEC));
+		const uint32_t nvec = (len - lead) / VEC, tail0 = lead + nvec * VEC;
+		if (threadIdx.x < lead) d[threadIdx.x] = s[threadIdx.x];
+		if (tail0 + threadIdx.x < len) d[tail0 + threadIdx.x] = s[tail0 + threadIdx.x];
+		// 16-byte loads on the SOURCE's grid too (an unaligned 16-byte load is split by the hardware: 3.6 TB/s): vector q
+		// of the output is words k .. k+3 of the aligned source vectors q and q + 1, k = the run's misalignment in
+		// 4-byte words (uniform); the next vector's words come from the next lane (the wave's last lane loads them)
+		const uint32_t kw = (uint32_t)(((uintptr_t)(s + lead) & 15u) >> 2);
+		const u32x4 *sa = reinterpret_cast<const u32x4 *>(reinterpret_cast<const unsigned char *>(s + lead) - 4u * kw);
+		u32x4 *dv = reinterpret_cast<u32x4 *>(d + lead);
+		const bool last_lane = (threadIdx.x & 63u) == 63u;
+#ifndef MSD_GATHER_NF
+#define MSD_GATHER_NF 2
+#endif
+		constexpr int NF = MSD_GATHER_NF; // loads in flight per thread
+		for (uint32_t q0 = 0; q0 < nvec; q0 += NF * 256) { // (every lane stays in the loop: its neighbour needs its words)
+			const uint32_t q = q0 + threadIdx.x;
+			u32x4 a[NF], nx[NF];
+#pragma unroll
+			for (int u = 0; u < NF; ++u) { // (beyond the chunk: its last vector again, ignored; with kw > 0 vector nvec holds the run's last words)
+				const uint32_t qq = min(q + u * 256u, kw ? nvec : nvec - 1u);
+				a[u] = sa[qq];
+				if (kw && last_lane) nx[u] = sa[min(qq + 1u, nvec)];
+			}
+#pragma unroll
+			for (int u = 0; u < NF; ++u) {
+				u32x4 o = a[u];
+				if (kw) { // (uniform)
+					// (the shuffles run with every lane active -- a lane that sat out would hand its neighbour zero)
+					const uint32_t sx = (uint32_t)__shfl_down((int)a[u].x, 1), sy = (uint32_t)__shfl_down((int)a[u].y, 1),
+						       sz = (uint32_t)__shfl_down((int)a[u].z, 1);
+					const uint32_t bx = last_lane ? nx[u].x : sx, by = last_lane ? nx[u].y : sy, bz = last_lane ? nx[u].z : sz;
+					o = kw == 1 ? u32x4{ a[u].y, a[u].z, a[u].w, bx } : kw == 2 ? u32x4{ a[u].z, a[u].w, bx, by } : u32x4{ a[u].w, bx, by, bz };
+				}
+				if (q + u * 256u < nvec) dv[q + u * 256u] = o;
+			}
+		}
+	}
+}
+
 // ------------------------------------------------- varying-bit reduction
 
 // OR and AND over keys[0], keys[stride], keys[2*stride], ...: bits where OR and AND differ

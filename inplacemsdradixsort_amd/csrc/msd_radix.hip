@@ -429,7 +429,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		     // single-pass mode (msd_partition_*): one round, caller-chosen digit
 		     bool single_pass, unsigned sp_shift, unsigned sp_width, uint64_t *sp_count,
 		     // ... or, instead of a digit, the key's range among nsplit ascending delimiters (msd_partition_by_splitters_*)
-		     const K *splitters = nullptr, uint32_t nsplit = 0)
+		     const K *splitters = nullptr, uint32_t nsplit = 0,
+		     // ... or a sort of nseg independent segments [seg_off[i], seg_off[i + 1]) on their low end_bit bits (msd_sort_*_segments)
+		     const uint64_t *seg_off = nullptr, uint32_t nseg = 0)
 {
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
@@ -450,6 +452,11 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		if (sp_width < 1 || sp_width > 8 || sp_shift + sp_width > sizeof(K) * 8)
 			return fail(c, MSD_EINVAL, "partition: radix_bits must be 1..8 and shift+radix_bits within the key");
 		cur.push_back({ 0, n, sp_shift + sp_width, 0 });
+	} else if (nseg) {
+		for (uint32_t i = 0; i < nseg; ++i) {
+			if (seg_off[i] > seg_off[i + 1] || seg_off[i + 1] > n) return fail(c, MSD_EINVAL, "segments: offsets must ascend and stay within n");
+			if (end_bit > 0 && seg_off[i + 1] - seg_off[i] > 1) cur.push_back({ seg_off[i], seg_off[i + 1] - seg_off[i], (uint32_t)end_bit, 0 });
+		}
 	} else if (end_bit > 0 && n > 1)
 		cur.push_back({ 0, n, (uint32_t)end_bit, 0 });
 
@@ -476,7 +483,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	// ---- leading-bit skipping: a cheap strided sample decides whether an exact OR/AND pass over
 	// all keys can pay off (it does when whole leading digits are constant, e.g. keys whose upper
 	// half is zero); all-equal inputs are finished here.
-	if (!single_pass && !cur.empty() && n >= 4096) {
+	if (!single_pass && !nseg && !cur.empty() && n >= 4096) {
 		unsigned long long *vres = reinterpret_cast<unsigned long long *>(ctr + 1);
 		auto run_vary = [&](uint64_t stride, uint64_t *vary_out) -> int {
 			const unsigned long long init[2] = { 0ull, ~0ull };
@@ -514,8 +521,46 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 
 	uint32_t nsmall_host = 0, ncount_host = 0, nbig_host = 0;
+	if (nseg && !cur.empty()) {
+		// segments that need no partition round go to the leaf lists at once, by collect_kernel's rules
+		std::vector<Segment> l_small, l_count, l_big, parents;
+		for (auto &sg : cur) {
+			const bool countable = !HV && sg.bits <= count_bits;
+			if (countable && sg.count >= 64 && sg.count <= std::max<uint64_t>(small_max, kCountMedMax))
+				l_count.push_back(sg);
+			else if (sg.count > small_max) {
+				if (countable && sg.count < 0xFFFF0000ull && l_big.size() < big_cap) l_big.push_back(sg); else parents.push_back(sg);
+			} else
+				l_small.push_back(sg);
+		}
+		int rc = lists_reserve(c, std::max(l_small.size(), l_count.size()) + 16, 0, 0);
+		if (!rc) rc = pinned_reserve(c, (l_small.size() + l_count.size() + l_big.size()) * sizeof(Segment) + sizeof(Counters));
+		if (rc) return rc;
+		small = c->lists;
+		small_count = c->lists + 3 * c->lists_cap;
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		Segment *ps = (Segment *)c->pinned;
+		auto up = [&](const std::vector<Segment> &v, Segment *dst) -> int {
+			if (v.empty()) return MSD_OK;
+			memcpy(ps, v.data(), v.size() * sizeof(Segment));
+			HIPCHK(c, hipMemcpyAsync(dst, ps, v.size() * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+			ps += v.size();
+			return MSD_OK;
+		};
+		if ((rc = up(l_small, small)) || (rc = up(l_count, small_count)) || (rc = up(l_big, big))) return rc;
+		nsmall_host = (uint32_t)l_small.size();
+		ncount_host = (uint32_t)l_count.size();
+		nbig_host = (uint32_t)l_big.size();
+		Counters *hc0 = (Counters *)ps; // the lists' counters continue from here
+		memset(hc0, 0, sizeof(Counters));
+		hc0->nsmall = nsmall_host;
+		hc0->ncount = ncount_host;
+		hc0->nbig = nbig_host;
+		HIPCHK(c, hipMemcpyAsync(ctr, hc0, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
+		cur = parents;
+	}
 	if constexpr (!HV) { // <= 16 open bits from the start (small key range): no partition round at all
-		if (!single_pass && !cur.empty() && n > small_max && cur[0].bits <= count_bits && n < 0xFFFF0000ull) {
+		if (!single_pass && !nseg && !cur.empty() && n > small_max && cur[0].bits <= count_bits && n < 0xFFFF0000ull) {
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			memcpy(c->pinned, &cur[0], sizeof(Segment));
 			HIPCHK(c, hipMemcpyAsync(big, c->pinned, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
@@ -523,7 +568,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			cur.clear();
 		}
 	}
-	if (!single_pass && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
+	if (!single_pass && !nseg && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(c->pinned, &cur[0], sizeof(Segment));
 		HIPCHK(c, hipMemcpyAsync(small, c->pinned, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
@@ -532,7 +577,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	}
 
 	int round = 0;
-	bool prev_direct = false; // the previous round placed its blocks directly (its digit was evenly spread)
+	// the previous round placed its blocks directly (its digit was evenly spread); segments handed in by the caller are
+	// taken to be such a round's children (the shards of a multi-GPU sort after their top-digit pass and exchange)
+	bool prev_direct = nseg != 0;
 	while (!cur.empty() || dev_np) {
 		// ---- segments that fit the registers of one workgroup take ONE register-resident pass (msd_regpart.hpp) instead
 		// of a general round: the last partition round of the tuple sort (65536 parents of about 2^14 tuples at 2^30)
@@ -1024,6 +1071,38 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 	return MSD_OK;
 }
 
+template <typename K>
+static int gather_impl(msd_ctx *c, K *dst, const K *src, const uint64_t *src_off, const uint64_t *dst_off, const uint64_t *len, uint32_t nruns)
+{
+	if (!c) return MSD_EINVAL;
+	if (nruns == 0) return MSD_OK;
+	if (!dst || !src || !src_off || !dst_off || !len) return fail(c, MSD_EINVAL, "gather: null pointer");
+	HIPCHK(c, hipSetDevice(c->device));
+	std::vector<GatherRun> runs;
+	uint64_t nchunks = 0;
+	for (uint32_t i = 0; i < nruns; ++i) {
+		if (!len[i]) continue;
+		runs.push_back({ src_off[i], dst_off[i], len[i], (uint32_t)nchunks, 0 });
+		nchunks += (len[i] + kGatherChunk - 1) / kGatherChunk;
+	}
+	if (runs.empty()) return MSD_OK;
+	if (nchunks >= 0xFFFFFFFFull) return fail(c, MSD_EINVAL, "gather: too many elements");
+	runs.push_back({ 0, 0, 0, (uint32_t)nchunks, 0 }); // sentinel
+	int rc = pinned_reserve(c, runs.size() * sizeof(GatherRun));
+	if (!rc) rc = slab_reserve(c, runs.size() * sizeof(GatherRun) + 4096); // (between sorts nothing in the slab is live)
+	if (rc) return rc;
+	HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
+	memcpy(c->pinned, runs.data(), runs.size() * sizeof(GatherRun));
+	GatherRun *d_runs = reinterpret_cast<GatherRun *>(c->slab);
+	HIPCHK(c, hipMemcpyAsync(d_runs, c->pinned, runs.size() * sizeof(GatherRun), hipMemcpyHostToDevice, c->stream));
+	// (one workgroup per 8 KiB chunk, no loop: 4.3-4.5 TB/s; persistent workgroups with larger chunks: 3.6)
+	const unsigned grid = (unsigned)nchunks;
+	hipLaunchKernelGGL((gather_runs_kernel<K>), dim3(grid), dim3(256), 0, c->stream, dst, src, (const GatherRun *)d_runs,
+			   (uint32_t)runs.size() - 1, (uint32_t)nchunks);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
 // ------------------------------------------------------------------ C ABI
 
 extern "C" {
@@ -1148,6 +1227,39 @@ int msd_partition_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, un
 	if (!c) return MSD_EINVAL;
 	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
 	return sort_impl<uint64_t, uint64_t>(c, k, r, n, 64, true, shift, rb, cnt);
+}
+
+// ---- segmented sort and run gather: what a rank of the multi-GPU sort does with the keys it received
+
+int msd_sort_u32_segments(msd_ctx *c, uint32_t *k, uint64_t n, const uint64_t *seg_off, uint32_t nseg, int end_bit)
+{
+	if (!c) return MSD_EINVAL;
+	if (nseg == 0) return MSD_OK;
+	if (!seg_off) return fail(c, MSD_EINVAL, "segments: null offsets");
+	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, end_bit, false, 0, 0, nullptr, nullptr, 0, seg_off, nseg);
+}
+int msd_sort_u64_segments(msd_ctx *c, uint64_t *k, uint64_t n, const uint64_t *seg_off, uint32_t nseg, int end_bit)
+{
+	if (!c) return MSD_EINVAL;
+	if (nseg == 0) return MSD_OK;
+	if (!seg_off) return fail(c, MSD_EINVAL, "segments: null offsets");
+	return sort_impl<uint64_t, NoVal>(c, k, nullptr, n, end_bit, false, 0, 0, nullptr, nullptr, 0, seg_off, nseg);
+}
+int msd_sort_pairs_u64_segments(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, const uint64_t *seg_off, uint32_t nseg, int end_bit)
+{
+	if (!c) return MSD_EINVAL;
+	if (nseg == 0) return MSD_OK;
+	if (!seg_off) return fail(c, MSD_EINVAL, "segments: null offsets");
+	return sort_impl<uint64_t, uint64_t>(c, k, r, n, end_bit, false, 0, 0, nullptr, nullptr, 0, seg_off, nseg);
+}
+
+int msd_gather_runs_u32(msd_ctx *c, uint32_t *dst, const uint32_t *src, const uint64_t *src_off, const uint64_t *dst_off, const uint64_t *len, uint32_t nruns)
+{
+	return gather_impl<uint32_t>(c, dst, src, src_off, dst_off, len, nruns);
+}
+int msd_gather_runs_u64(msd_ctx *c, uint64_t *dst, const uint64_t *src, const uint64_t *src_off, const uint64_t *dst_off, const uint64_t *len, uint32_t nruns)
+{
+	return gather_impl<uint64_t>(c, dst, src, src_off, dst_off, len, nruns);
 }
 
 // ---- splitter service (reference: sampling src/msb_64.c:1511-1521, extract_delimiters :1304-1322, range function :188-204)

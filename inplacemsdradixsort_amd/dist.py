@@ -97,19 +97,81 @@ def exchange_counts(dist, send, capacity: int, world: int, group=None):
     return mat[me, :world].tolist(), mat[:, me].tolist()
 
 
-def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None):
+def exchange_bucket_counts(dist, counts, capacity: int, world: int, group=None):
+    """Like :func:`exchange_counts`, at the granularity of the 256 top-digit buckets: every rank learns every rank's
+    bucket sizes (one all-gather of 257 int64 per rank).  Returns (send_list, recv_list, mine): ``mine[s][j]`` = keys of
+    this rank's j-th bucket that source rank s holds -- the lengths of the runs this rank receives, in arrival order."""
+    import torch
+    row = torch.cat([counts.to(torch.int64), torch.tensor([capacity], dtype=torch.int64, device=counts.device)])
+    rows = [torch.empty_like(row) for _ in range(world)]
+    dist.all_gather(rows, row, group=group)
+    mat = torch.stack(rows).cpu()                                # [sender, bucket | capacity]: one D2H
+    per = 256 // world
+    to_rank = mat[:, :256].view(world, world, per).sum(dim=2)    # [sender, destination]
+    totals, caps = to_rank.sum(dim=0), mat[:, 256]
+    over = [(r, int(totals[r]), int(caps[r])) for r in range(world) if int(totals[r]) > int(caps[r])]
+    if over:
+        raise ReceiveOverflow("receive buffer too small on rank(s) " +
+                              ", ".join(f"{r}: {t} keys for capacity {c}" for r, t, c in over) +
+                              " (raise the slack -- the reference's fudge -- or use sort_sharded_u32_sampled)")
+    me = _rank(dist, group)
+    return to_rank[me].tolist(), to_rank[:, me].tolist(), mat[:, me * per:(me + 1) * per].tolist()
+
+
+def bucket_major(mine):
+    """The runs a rank received (``mine[s][j]``: source-major, as the all-to-all delivers them) and where each belongs
+    when every bucket is to be contiguous: (src_off, dst_off, lens) for ``engine.gather_runs`` and the bucket
+    boundaries ``seg_off`` for ``engine.sort_segments``."""
+    world, per = len(mine), len(mine[0])
+    src_off, dst_off, lens = [], [], []
+    bucket_start, at = [], 0
+    for j in range(per):
+        bucket_start.append(at)
+        at += sum(int(mine[s][j]) for s in range(world))
+    seg_off = bucket_start + [at]
+    pos = 0
+    fill = list(bucket_start)
+    for s in range(world):
+        for j in range(per):
+            n = int(mine[s][j])
+            src_off.append(pos)
+            dst_off.append(fill[j])
+            lens.append(n)
+            pos += n
+            fill[j] += n
+    return src_off, dst_off, lens, seg_off
+
+
+def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None):
     """Sorts the union of all ranks' ``keys`` (int32 tensors holding u32 bit patterns).
-    Returns this rank's sorted range as a view of ``recv``; rank r's range precedes rank r+1's."""
+    Returns this rank's sorted range; rank r's range precedes rank r+1's.
+
+    With a second buffer ``work`` (as large as ``recv``) the local sort does not repeat the top-digit pass: the runs
+    that arrived (per source, that source's buckets of this rank's range) are gathered bucket-major into ``work`` in
+    one launch and sorted there as segments on the remaining 24 bits -- the result is a view of ``work``.  Without it
+    the received keys are sorted in ``recv`` on all ``32 - log2(world)`` bits."""
     lg = _log2(world)
     if world == 1:
         engine.sort_u32(keys)
         return keys
     counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
-    send = counts.view(world, 256 // world).sum(dim=1)           # keys per destination rank
-    send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
-    out = recv[:int(sum(got_l))]
-    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
-    engine.sort_u32(out, end_bit=32 - lg)
+    if work is None:
+        send = counts.view(world, 256 // world).sum(dim=1)       # keys per destination rank
+        send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
+        out = recv[:int(sum(got_l))]
+        dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+        engine.sort_u32(out, end_bit=32 - lg)
+        return out
+    send_l, got_l, mine = exchange_bucket_counts(dist, counts, min(recv.numel(), work.numel()), world, group)
+    m = int(sum(got_l))
+    dist.all_to_all_single(recv[:m], keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    return _gather_and_sort(engine, recv[:m], work[:m], mine)
+
+
+def _gather_and_sort(engine, arrived, out, mine):
+    src_off, dst_off, lens, seg_off = bucket_major(mine)
+    engine.gather_runs(out, arrived, src_off, dst_off, lens)
+    engine.sort_segments(out, seg_off, 24)
     return out
 
 
@@ -167,12 +229,17 @@ class ShardedSorter:
     untouched until the matching ``collect`` returns.
     """
 
-    def __init__(self, engine, dist, world: int, recv_bufs, group=None):
+    def __init__(self, engine, dist, world: int, recv_bufs, group=None, work_bufs=None):
         self.engine, self.dist, self.world, self.group = engine, dist, world, group
         self.lg = _log2(world)
         self.recv = list(recv_bufs)
         if world > 1 and len(self.recv) < 2:
             raise ValueError("ShardedSorter needs two receive buffers")
+        # work buffers: the arrived runs are gathered bucket-major into one of them and sorted there as segments on
+        # 24 bits (the local sort does not repeat the top-digit pass); collect() then returns a view of a WORK buffer,
+        # overwritten len(work_bufs) collects later.  Without them the keys are sorted where they arrived.
+        self.work = list(work_bufs) if work_bufs else []
+        self._wslot = 0
         self._slot = 0
         self._pending = []
 
@@ -186,24 +253,36 @@ class ShardedSorter:
 
     def submit(self, keys) -> None:
         if self.world == 1:
-            self._pending.append((keys, None, keys))
+            self._pending.append((keys, None, None))
             return
         if len(self._pending) >= len(self.recv):
             raise RuntimeError("collect() before submitting more shards than there are receive buffers")
         counts = self.engine.partition(keys, 24, 8)
-        send = counts.view(self.world, 256 // self.world).sum(dim=1)
         recv = self.recv[self._slot]
-        send_l, got_l = exchange_counts(self.dist, send, recv.numel(), self.world, self.group)  # raises on all ranks
+        mine = None
+        if self.work:
+            cap = min(recv.numel(), min(w.numel() for w in self.work))
+            send_l, got_l, mine = exchange_bucket_counts(self.dist, counts, cap, self.world, self.group)  # raises on all ranks
+        else:
+            send = counts.view(self.world, 256 // self.world).sum(dim=1)
+            send_l, got_l = exchange_counts(self.dist, send, recv.numel(), self.world, self.group)        # raises on all ranks
         self._slot = (self._slot + 1) % len(self.recv)
         out = recv[:int(sum(got_l))]
-        self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), keys))
+        self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), mine))
 
     def collect(self):
-        out, work, _keys = self._pending.pop(0)
-        if work is not None:
-            work.wait()
-        self.engine.sort_u32(out, end_bit=32 - self.lg)
-        return out
+        out, handle, mine = self._pending.pop(0)
+        if handle is not None:
+            handle.wait()
+        if mine is None:
+            if self.world > 1:
+                self.engine.sort_u32(out, end_bit=32 - self.lg)
+            else:
+                self.engine.sort_u32(out)
+            return out
+        final = self.work[self._wslot][:out.numel()]
+        self._wslot = (self._wslot + 1) % len(self.work)
+        return _gather_and_sort(self.engine, out, final, mine)
 
     def pending(self) -> int:
         return len(self._pending)

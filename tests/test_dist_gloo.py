@@ -28,6 +28,19 @@ class NumpyEngine:
             r[:] = r[order]
         return torch.from_numpy(np.bincount(d, minlength=1 << radix_bits).astype(np.int64))
 
+    def gather_runs(self, dst, src, src_off, dst_off, lens):
+        d, s_ = dst.numpy(), src.numpy()
+        for so, do, n in zip(src_off, dst_off, lens):
+            d[do:do + n] = s_[so:so + n]
+
+    def sort_segments(self, keys, seg_off, end_bit, rids=None):
+        a = keys.numpy().view(np.uint32 if keys.element_size() == 4 else np.uint64)
+        for lo, hi in zip(seg_off[:-1], seg_off[1:]):
+            if hi > lo:
+                hb = a[lo:hi] >> a.dtype.type(end_bit)
+                assert int(hb.min()) == int(hb.max())           # a segment's keys agree above end_bit
+                a[lo:hi].sort()
+
     def sort_u64(self, keys, end_bit=64):
         a = keys.numpy().view(np.uint64)
         if a.size and end_bit < 64:
@@ -86,20 +99,24 @@ def _worker(rank, world, port, n, kind, q, sampled=False):
         k = O.gen_zipf_u32(n, first=rank * n)
     keys = torch.from_numpy(k.view(np.int32).copy())
     recv = torch.empty(n * world, dtype=torch.int32)
-    fn = sort_sharded_u32_sampled if sampled else sort_sharded_u32
-    out = fn(NumpyEngine(), keys, recv, dist, world)
+    if sampled == "work":   # gather bucket-major into a second buffer, segmented local sort
+        out = sort_sharded_u32(NumpyEngine(), keys, recv, dist, world, work=torch.empty(n * world, dtype=torch.int32))
+    else:
+        fn = sort_sharded_u32_sampled if sampled else sort_sharded_u32
+        out = fn(NumpyEngine(), keys, recv, dist, world)
     q.put((rank, out.numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind", [(2, "uniform"), (4, "uniform"), (2, "zipf"), (8, "uniform")])
-def test_sharded_sort_over_gloo(world, kind):
+@pytest.mark.parametrize("world,kind,work", [(2, "uniform", False), (4, "uniform", False), (2, "zipf", False), (8, "uniform", False),
+                                             (2, "zipf", True), (4, "uniform", True), (8, "uniform", True)])
+def test_sharded_sort_over_gloo(world, kind, work):
     n = 20000 if world < 8 else 6000   # (8 ranks: each owns 32 top-digit buckets, BASELINE config C4's geometry)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q, "work" if work else False)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
@@ -125,7 +142,8 @@ def _pipeline_worker(rank, world, port, n, shards, q):
     from oracle import oracle as O
     bufs = [torch.from_numpy(O.gen_uniform_u32(n, seed=100 + s, first=rank * n).view(np.int32).copy()) for s in range(shards)]
     recv = [torch.empty(n * world, dtype=torch.int32) for _ in range(2)]
-    sorter = ShardedSorter(NumpyEngine(), dist, world, recv)
+    work = [torch.empty(n * world, dtype=torch.int32) for _ in range(2)] if world != 2 else None   # (2 ranks: sorted where they arrive)
+    sorter = ShardedSorter(NumpyEngine(), dist, world, recv, work_bufs=work)
     outs = []
     for s in range(shards):        # the order bench.py uses: submit shard s, then finish shard s-1
         sorter.submit(bufs[s])

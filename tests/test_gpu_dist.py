@@ -56,7 +56,10 @@ def _worker(rank, world, port, n, kind, q, sampled=False):
     (ctx.gen_uniform_u32 if kind == "uniform" else ctx.gen_zipf_u32)(keys, first=rank * n)
     v0, s0, x0 = ctx.check(keys)
     recv = torch.empty(n * world, dtype=torch.int32, device="cuda:0")
-    out = (sort_sharded_u32_sampled if sampled else sort_sharded_u32)(ctx, keys, recv, GlooViaCpu, world)
+    if sampled == "work":   # runs gathered bucket-major into a second buffer, segmented local sort (bench.py's N > 1 path)
+        out = sort_sharded_u32(ctx, keys, recv, GlooViaCpu, world, work=torch.empty(n * world, dtype=torch.int32, device="cuda:0"))
+    else:
+        out = (sort_sharded_u32_sampled if sampled else sort_sharded_u32)(ctx, keys, recv, GlooViaCpu, world)
     v, s, x = ctx.check(out)
     lo = int(out[0].item()) & 0xFFFFFFFF if out.numel() else -1
     hi = int(out[-1].item()) & 0xFFFFFFFF if out.numel() else -1
@@ -81,7 +84,8 @@ def _pipeline_worker(rank, world, port, n, shards, q):
         bufs.append(t)
         sums.append(ctx.check(t)[1:])
     recv = [torch.empty(n * world, dtype=torch.int32, device="cuda:0") for _ in range(2)]
-    sorter = ShardedSorter(ctx, GlooViaCpu, world, recv)
+    work = [torch.empty(n * world, dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    sorter = ShardedSorter(ctx, GlooViaCpu, world, recv, work_bufs=work)
     res = []
 
     def take(out):
@@ -129,12 +133,13 @@ def test_pipelined_sharded_sorter_real_engine():
         assert per_rank[0][5] < per_rank[1][4]                        # rank 0's range precedes rank 1's
 
 
-@pytest.mark.parametrize("world,kind,n", [(2, "uniform", 1 << 22), (4, "uniform", 1 << 20), (2, "zipf", 1 << 21)])
-def test_sharded_sort_real_engine(world, kind, n):
+@pytest.mark.parametrize("world,kind,n,work", [(2, "uniform", 1 << 22, False), (4, "uniform", 1 << 20, False), (2, "zipf", 1 << 21, False),
+                                               (2, "uniform", 1 << 22, True), (4, "zipf", 1 << 20, True)])
+def test_sharded_sort_real_engine(world, kind, n, work):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, n, kind, q)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n, kind, q, "work" if work else False)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
