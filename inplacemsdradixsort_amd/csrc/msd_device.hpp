@@ -919,7 +919,10 @@ __device__ __forceinline__ int slot_owner_guess(const uint32_t *is, const uint32
 // Pass 2 (SCATTER = true): write the per-child lists, interior-class entries first.
 // Global atomics are issued once per (workgroup, child, class) / once per wave (holes);
 // positions inside a reservation come from LDS fetch-adds.
-constexpr uint32_t kSlotParts = 4;
+#ifndef MSD_SLOT_PARTS // (overridable for experiments)
+#define MSD_SLOT_PARTS 2
+#endif
+constexpr uint32_t kSlotParts = MSD_SLOT_PARTS;
 template <bool SCATTER>
 __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__restrict__ stripes,
 	const Parent *__restrict__ parents, const uint8_t *__restrict__ block_map,
@@ -931,9 +934,10 @@ __global__ __launch_bounds__(256) void slot_classify_kernel(const Stripe *__rest
 	// direct kernel ran: the plan did not decline, or the mode forces it)
 	const uint8_t *slot_full = (slot_full_arg && (force || ctr->direct_uneven == 0)) ? slot_full_arg : nullptr;
 	__shared__ uint32_t s_is[kP], s_ie[kP], s_cls[2][kP], s_base[2][kP];
-	// kSlotParts workgroups share a stripe (each a contiguous part of its slots): the sweeps are short
-	// latency-bound loops, so more, smaller workgroups finish sooner; counts and list ranges are
-	// combined across workgroups by atomics anyway
+	// kSlotParts workgroups share a stripe (each a contiguous part of its slots); counts and list ranges are combined
+	// across workgroups by atomics anyway.  Measured per launch pair at 2^30 u32 keys: 1 part 0.43 ms, 2 parts 0.37,
+	// 4 parts 0.44, 8 parts 0.53 -- more workgroups shorten each sweep but every one pays the same chain of dependent
+	// look-ups (stripe, parent, child geometry) and its fetch-adds on the shared counters
 	Stripe st = stripes[blockIdx.x / kSlotParts];
 	const Parent pa = parents[st.parent];
 	const uint32_t W = 1u << pa.width, tid = threadIdx.x;
@@ -1584,7 +1588,10 @@ namespace msd {
 // workgroup then leaves the segment untouched and queues it for the general LDS sort.
 constexpr int kCountTh = 1024;
 constexpr int kCountMaxBits = 16;
-constexpr uint64_t kCountMedMax = 1ull << 17; // largest segment one workgroup counts by itself
+#ifndef MSD_COUNT_MED_LOG // (overridable for experiments)
+#define MSD_COUNT_MED_LOG 17
+#endif
+constexpr uint64_t kCountMedMax = 1ull << MSD_COUNT_MED_LOG; // largest segment one workgroup counts by itself
 // counter word i lives at i + i/32: a thread's 16 consecutive words and its neighbours' then
 // fall on different LDS banks (unpadded, the stride-16 walk is a 32-way bank conflict)
 constexpr size_t kCountCwBytes = (((size_t)1 << kCountMaxBits) / 4 + ((size_t)1 << kCountMaxBits) / 128 + 4) * 4;
