@@ -251,10 +251,12 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 	for (auto &s : segs) total += s.count;
 	rp.round_keys = total;
 	// stripe length: enough stripes to fill the chip a few times over, whole tiles
-	uint64_t want = std::max<uint64_t>(1, (uint64_t)sm_count * 4);
+	static const int want_mul = getenv("MSD_STRIPE_WANT") ? atoi(getenv("MSD_STRIPE_WANT")) : 4;         // (experiments)
+	static const int cap_log = getenv("MSD_STRIPE_CAP_LOG") ? atoi(getenv("MSD_STRIPE_CAP_LOG")) : 20;
+	uint64_t want = std::max<uint64_t>(1, (uint64_t)sm_count * want_mul);
 	uint64_t slen = (total + want - 1) / want;
 	slen = std::max<uint64_t>(slen, 4 * T);
-	slen = std::min<uint64_t>(slen, (uint64_t)1 << 20);
+	slen = std::min<uint64_t>(slen, (uint64_t)1 << cap_log);
 	slen = (slen + T - 1) / T * T;
 	for (auto &s : segs) {
 		Parent p;
