@@ -117,7 +117,11 @@ class MsdContext:
     # ---- a rank of the multi-GPU sort after its exchange (reference: local sorting of whole key ranges, src/msb_64.c:2200-2255)
     @staticmethod
     def _u64arr(xs):
-        return (C.c_uint64 * len(xs))(*[int(x) for x in xs])
+        """Host array of uint64 for the C ABI (a numpy array goes through without a per-element conversion)."""
+        a = np.ascontiguousarray(xs, dtype=np.uint64)
+        p = a.ctypes.data_as(C.POINTER(C.c_uint64))
+        p._keep = a   # the array must outlive the call
+        return p
 
     def sort_segments(self, keys, seg_off, end_bit: int, rids=None) -> None:
         """Sorts the independent segments [seg_off[i], seg_off[i+1]) on their low ``end_bit`` bits in one call

@@ -2511,11 +2511,13 @@ constexpr uint32_t kGatherChunk = MSD_GATHER_CHUNK;
 
 template <typename K>
 __global__ __launch_bounds__(256) void gather_runs_kernel(K *__restrict__ dst, const K *__restrict__ src,
-	const GatherRun *__restrict__ runs, uint32_t nruns, uint32_t nchunks)
+	const GatherRun *__restrict__ runs, uint32_t nruns, uint32_t nchunks, const uint32_t *__restrict__ coarse)
 {
 	constexpr int VEC = 16 / (int)sizeof(K);
 	for (uint32_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-		uint32_t lo = 0, hi = nruns; // runs[lo].first_chunk <= c < runs[hi].first_chunk
+		// coarse[i] = the run of chunk 64 i: a workgroup lives for a few microseconds, a search over all runs from
+		// scratch (eleven dependent look-ups for 2048 runs) would be a good part of them
+		uint32_t lo = coarse[c >> 6], hi = min(coarse[(c >> 6) + 1] + 1u, nruns); // runs[lo].first_chunk <= c < runs[hi].first_chunk
 		while (hi - lo > 1) {
 			const uint32_t mid = (lo + hi) >> 1;
 			if (runs[mid].first_chunk <= c) lo = mid; else hi = mid;

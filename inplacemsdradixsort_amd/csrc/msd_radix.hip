@@ -1090,17 +1090,27 @@ static int gather_impl(msd_ctx *c, K *dst, const K *src, const uint64_t *src_off
 	if (runs.empty()) return MSD_OK;
 	if (nchunks >= 0xFFFFFFFFull) return fail(c, MSD_EINVAL, "gather: too many elements");
 	runs.push_back({ 0, 0, 0, (uint32_t)nchunks, 0 }); // sentinel
-	int rc = pinned_reserve(c, runs.size() * sizeof(GatherRun));
-	if (!rc) rc = slab_reserve(c, runs.size() * sizeof(GatherRun) + 4096); // (between sorts nothing in the slab is live)
+	const size_t nreal = runs.size() - 1, ncoarse = (size_t)(nchunks >> 6) + 2;
+	std::vector<uint32_t> coarse(ncoarse); // the run of every 64th chunk
+	for (size_t i = 0, r = 0; i < ncoarse; ++i) {
+		const uint64_t ch = std::min<uint64_t>((uint64_t)i << 6, nchunks - 1);
+		while (r + 1 < nreal && runs[r + 1].first_chunk <= ch) ++r;
+		coarse[i] = (uint32_t)r;
+	}
+	const size_t runs_bytes = align_up(runs.size() * sizeof(GatherRun), 256), bytes = runs_bytes + ncoarse * sizeof(uint32_t);
+	int rc = pinned_reserve(c, bytes);
+	if (!rc) rc = slab_reserve(c, bytes + 4096); // (between sorts nothing in the slab is live)
 	if (rc) return rc;
 	HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
 	memcpy(c->pinned, runs.data(), runs.size() * sizeof(GatherRun));
+	memcpy((char *)c->pinned + runs_bytes, coarse.data(), ncoarse * sizeof(uint32_t));
 	GatherRun *d_runs = reinterpret_cast<GatherRun *>(c->slab);
-	HIPCHK(c, hipMemcpyAsync(d_runs, c->pinned, runs.size() * sizeof(GatherRun), hipMemcpyHostToDevice, c->stream));
+	const uint32_t *d_coarse = reinterpret_cast<const uint32_t *>(c->slab + runs_bytes);
+	HIPCHK(c, hipMemcpyAsync(d_runs, c->pinned, bytes, hipMemcpyHostToDevice, c->stream));
 	// (one workgroup per 8 KiB chunk, no loop: 4.3-4.5 TB/s; persistent workgroups with larger chunks: 3.6)
 	const unsigned grid = (unsigned)nchunks;
 	hipLaunchKernelGGL((gather_runs_kernel<K>), dim3(grid), dim3(256), 0, c->stream, dst, src, (const GatherRun *)d_runs,
-			   (uint32_t)runs.size() - 1, (uint32_t)nchunks);
+			   (uint32_t)runs.size() - 1, (uint32_t)nchunks, d_coarse);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }
