@@ -17,22 +17,32 @@
 //   * blocks without a consumed slot in their own piece ("steals") are handled by the bucket waves BEHIND
 //     the job barrier, together with the choice of the next reads, while the other waves flush; the
 //     tile loop has three workgroup barriers and no conditional fourth.
-//   * 512-thread workgroups, two per CU (128 VGPRs per lane instead of 64: nothing spills), tiles of 8192
-//     u32 keys: the per-bucket bookkeeping is paid half as often per key.
+//   * 512-thread workgroups, two per CU (128 VGPRs per lane instead of 64: nothing spills), tiles of 4096
+//     u32 / 2048 u64 keys (two 16-byte vectors per thread; the sweep is recorded at Direct2Cfg below).
 #pragma once
 
 namespace msd {
 
 template <typename K, typename V> struct Direct2Cfg;
-#ifndef MSD_D2_TH // (overridable for experiments: tools/variants.sh)
+// (overridable for experiments, tools/variant_run.py.  2^30 u32 keys, per launch: 512 threads x 2 vectors 1.88 ms,
+// x 4 vectors 1.97, x 1 vector 2.12; 384 x 4: 2.26; 640 x 2: 1.98; 1024 x 1: 2.33)
+#ifndef MSD_D2_TH
 #define MSD_D2_TH 512
-#define MSD_D2_NV 4
+#define MSD_D2_NV 2
 #define MSD_D2_WPE 4
 #endif
 template <> struct Direct2Cfg<uint32_t, NoVal> { static constexpr int TH = MSD_D2_TH, NV = MSD_D2_NV, WPE = MSD_D2_WPE; };
-template <> struct Direct2Cfg<uint64_t, NoVal> { static constexpr int TH = 512, NV = 4, WPE = 4; };
+#ifndef MSD_D2K_TH // (u64 keys, overridable for experiments; 2^30 keys: two vectors per thread 3.97 ms per round, four 4.15, one 4.68)
+#define MSD_D2K_TH 512
+#define MSD_D2K_NV 2
+#define MSD_D2K_WPE 4
+#endif
+template <> struct Direct2Cfg<uint64_t, NoVal> { static constexpr int TH = MSD_D2K_TH, NV = MSD_D2K_NV, WPE = MSD_D2K_WPE; };
 // tuples: key and payload buffers fill the LDS, one workgroup per CU
-template <> struct Direct2Cfg<uint64_t, uint64_t> { static constexpr int TH = 1024, NV = 2, WPE = 4; };
+#ifndef MSD_D2P_NV // (tuples, overridable for experiments; 2^30 tuples: two vectors per thread 6.15 ms per round, one 6.31, four 9.9)
+#define MSD_D2P_NV 2
+#endif
+template <> struct Direct2Cfg<uint64_t, uint64_t> { static constexpr int TH = 1024, NV = MSD_D2P_NV, WPE = 4; };
 
 template <typename K, typename V> struct Direct2Lds {
 	using C = Cfg<K, V>;
