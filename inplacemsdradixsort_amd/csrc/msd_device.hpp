@@ -689,9 +689,18 @@ __global__ __launch_bounds__(256) void direct_sample_kernel(const K *__restrict_
 // device-scope add per non-empty digit.  A read-only pass: 4 B per u32 key.
 template <typename K>
 __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__ keys, const Stripe *__restrict__ stripes,
-	const Parent *__restrict__ parents, DirectPlan *__restrict__ plans)
+	const Parent *__restrict__ parents, DirectPlan *__restrict__ plans,
+	// != nullptr: also OR and AND of all keys (vres[0] |= OR, vres[1] &= AND, as vary_kernel does) -- the exact check behind
+	// a leading-bit skip that was decided from a sample rides on this read
+	unsigned long long *__restrict__ vres)
 {
 	constexpr int VEC = Vec16<K>::N;
+	K v_or = 0, v_and = ~(K)0;
+	auto seen_key = [&](K k) {
+		v_or |= k;
+		v_and &= k;
+		return k;
+	};
 	__shared__ uint32_t h[kP];
 	const Stripe st = stripes[blockIdx.x];
 	const Parent pa = parents[st.parent];
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 	__syncthreads();
 	const uint64_t a0 = (st.begin + VEC - 1) / VEC * VEC, a1 = st.end / VEC * VEC; // 16-byte aligned part
 	if (a0 < a1) {
-		for (uint64_t i = st.begin + tid; i < a0; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+		for (uint64_t i = st.begin + tid; i < a0; i += 1024) atomicAdd(&h[digit_of(seen_key(keys[i]), shift, mask)], 1u);
 		const uint32_t nvec = (uint32_t)((a1 - a0) / VEC); // (a stripe has at most 2^20 elements)
 		const K *kp = keys + a0;                           // uniform base, 32-bit offsets, loads branch-free
 		constexpr int U = 8;
@@ -723,17 +732,29 @@ __global__ __launch_bounds__(1024) void direct_hist_kernel(const K *__restrict__
 			for (int u = 0; u < U; ++u) {
 				if (v + (uint32_t)u * 1024u < nvec) {
 #pragma unroll
-					for (int e = 0; e < VEC; ++e) atomicAdd(&h[digit_of(kk[u][e], shift, mask)], 1u);
+					for (int e = 0; e < VEC; ++e) atomicAdd(&h[digit_of(seen_key(kk[u][e]), shift, mask)], 1u);
 					seen += 1;
 					same += digit_of(kk[u][0], shift, mask) == digit_of(kk[u][VEC - 1], shift, mask) ? 1u : 0u;
 				}
 			}
 		}
-		for (uint64_t i = a1 + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+		for (uint64_t i = a1 + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(seen_key(keys[i]), shift, mask)], 1u);
 	} else
-		for (uint64_t i = st.begin + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(keys[i], shift, mask)], 1u);
+		for (uint64_t i = st.begin + tid; i < st.end; i += 1024) atomicAdd(&h[digit_of(seen_key(keys[i]), shift, mask)], 1u);
 	__syncthreads();
 	if (tid < kP && h[tid]) atomicAdd(&plans[st.parent].est_cnt[tid], h[tid]);
+	if (vres) { // (uniform)
+		unsigned long long o = (unsigned long long)v_or, a = (unsigned long long)v_and | (sizeof(K) == 4 ? 0xFFFFFFFF00000000ull : 0ull);
+#pragma unroll
+		for (int s = 32; s > 0; s >>= 1) {
+			o |= __shfl_xor(o, s);
+			a &= __shfl_xor(a, s);
+		}
+		if ((tid & 63) == 0) {
+			atomicOr(&vres[0], o);
+			atomicAnd(&vres[1], a);
+		}
+	}
 	// first and last key of every 16-byte vector: equal digits nearly always <=> locally sorted / runs
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {

@@ -485,39 +485,57 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	// ---- leading-bit skipping: a cheap strided sample decides whether an exact OR/AND pass over
 	// all keys can pay off (it does when whole leading digits are constant, e.g. keys whose upper
 	// half is zero); all-equal inputs are finished here.
+	unsigned long long *vres = reinterpret_cast<unsigned long long *>(ctr + 1);
+	auto vres_init = [&]() -> int { // OR accumulator 0, AND accumulator all ones (no host round trip)
+		HIPCHK(c, hipMemsetAsync(vres, 0x00, sizeof(unsigned long long), c->stream));
+		HIPCHK(c, hipMemsetAsync(vres + 1, 0xFF, sizeof(unsigned long long), c->stream));
+		return MSD_OK;
+	};
+	auto run_vary = [&](uint64_t stride, uint64_t *vary_out) -> int {
+		int rc0 = vres_init();
+		if (rc0) return rc0;
+		const uint64_t cnt = (n + stride - 1) / stride;
+		const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (cnt + 255) / 256);
+		hipLaunchKernelGGL((vary_kernel<K>), dim3(grid), dim3(256), 0, c->stream, keys, n, stride, vres);
+		HIPCHK(c, hipGetLastError());
+		HIPCHK(c, hipMemcpyAsync(c->pinned, vres, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		const unsigned long long *h = (const unsigned long long *)c->pinned;
+		*vary_out = h[0] ^ h[1];
+		return MSD_OK;
+	};
+	const uint64_t low_mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
+	// A skip decided from the sample alone is `unverified`: the rounds only permute keys, so the exact check may come
+	// later -- on the exact histogram pass of the second round if that reads every key (it costs that pass nothing:
+	// 1.4 ms less for 2^30 tuples with 32 constant key bits), else in a pass of its own before the leaves, which
+	// re-generate keys from a common prefix and must not run on a wrong one.  If the check fails (some key differs
+	// in a bit the sample found constant) the sort starts over on all bits the exact pass found varying: the data is
+	// still the same multiset.
+	bool unverified = false;
+	uint64_t claimed_const = 0; // bits below end_bit the sample found constant
 	if (!single_pass && !nseg && !cur.empty() && n >= 4096) {
-		unsigned long long *vres = reinterpret_cast<unsigned long long *>(ctr + 1);
-		auto run_vary = [&](uint64_t stride, uint64_t *vary_out) -> int {
-			const unsigned long long init[2] = { 0ull, ~0ull };
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			memcpy(c->pinned, init, sizeof init);
-			HIPCHK(c, hipMemcpyAsync(vres, c->pinned, sizeof init, hipMemcpyHostToDevice, c->stream));
-			const uint64_t cnt = (n + stride - 1) / stride;
-			const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (cnt + 255) / 256);
-			hipLaunchKernelGGL((vary_kernel<K>), dim3(grid), dim3(256), 0, c->stream, keys, n, stride, vres);
-			HIPCHK(c, hipGetLastError());
-			HIPCHK(c, hipMemcpyAsync(c->pinned, vres, sizeof init, hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(c, hipStreamSynchronize(c->stream));
-			const unsigned long long *h = (const unsigned long long *)c->pinned;
-			*vary_out = h[0] ^ h[1];
-			return MSD_OK;
-		};
-		const uint64_t low_mask = end_bit >= 64 ? ~0ull : ((1ull << end_bit) - 1ull);
 		uint64_t vary = 0;
 		int rc = run_vary(std::max<uint64_t>(1, n / 8192), &vary);
 		if (rc) return rc;
 		vary &= low_mask;
 		const int top_sample = vary ? 64 - __builtin_clzll(vary) : 0;
-		if (top_sample + 8 <= end_bit) { // at least one whole leading digit looks constant: make sure
-			rc = run_vary(1, &vary);
-			if (rc) return rc;
-			vary &= low_mask;
-			const int top = vary ? 64 - __builtin_clzll(vary) : 0;
-			set_stat(c, "skipped_bits", (uint64_t)(end_bit - top));
-			if (top == 0)
-				cur.clear(); // every key is the same on the bits in question: already sorted
-			else
-				cur[0].bits = (uint32_t)top;
+		if (top_sample + 8 <= end_bit) { // at least one whole leading digit looks constant
+			if (top_sample > 0 && c->direct_mode != 0 && n >= c->direct_min && n >= ((uint64_t)1 << 24)) {
+				unverified = true;
+				claimed_const = low_mask & ~(((uint64_t)1 << top_sample) - 1ull);
+				cur[0].bits = (uint32_t)top_sample;
+				set_stat(c, "skipped_bits", (uint64_t)(end_bit - top_sample));
+			} else { // make sure at once
+				rc = run_vary(1, &vary);
+				if (rc) return rc;
+				vary &= low_mask;
+				const int top = vary ? 64 - __builtin_clzll(vary) : 0;
+				set_stat(c, "skipped_bits", (uint64_t)(end_bit - top));
+				if (top == 0)
+					cur.clear(); // every key is the same on the bits in question: already sorted
+				else
+					cur[0].bits = (uint32_t)top;
+			}
 		}
 		phase_mark(c, "bit skip");
 	}
@@ -582,6 +600,25 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	// the previous round placed its blocks directly (its digit was evenly spread); segments handed in by the caller are
 	// taken to be such a round's children (the shards of a multi-GPU sort after their top-digit pass and exchange)
 	bool prev_direct = nseg != 0;
+	// the sort starts over from here if the exact check behind a sampled leading-bit skip fails: on `exact_vary`, the
+	// bits that really vary
+	auto start_over = [&](uint64_t exact_vary) -> int {
+		exact_vary &= low_mask;
+		const int top = exact_vary ? 64 - __builtin_clzll(exact_vary) : 0;
+		set_stat(c, "skipped_bits", (uint64_t)(end_bit - top));
+		add_stat(c, "bit_skip_restarts", 1);
+		cur.clear();
+		if (top > 0) cur.push_back({ 0, n, (uint32_t)top, 0 });
+		nsmall_host = ncount_host = nbig_host = 0;
+		dev_np = 0;
+		prev_direct = false;
+		unverified = false;
+		HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
+		return MSD_OK;
+	};
+	bool again = true;
+	while (again) {
+	again = false;
 	while (!cur.empty() || dev_np) {
 		// ---- segments that fit the registers of one workgroup take ONE register-resident pass (msd_regpart.hpp) instead
 		// of a general round: the last partition round of the tuple sort (65536 parents of about 2^14 tuples at 2^30)
@@ -728,7 +765,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		phase_mark(c, "plan+upload");
 
 		// ---- A: classify (histogram falls out of it)
-		bool tried_direct = false;
+		bool tried_direct = false, hist_checks = false;
 		// Direct placement (DESIGN.md section 2, A'): the first round from a sample, later rounds -- only
 		// after a direct first round -- from exact counts (a read-only pass).
 		// (the read schedule hands a bucket one slot per tile: with fewer than 256 buckets the tiles
@@ -754,8 +791,17 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				const uint32_t every = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(1, nruns / 16384));
 				const uint32_t sgrid = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, nruns / every / 4));
 				hipLaunchKernelGGL((direct_sample_kernel<K>), dim3(sgrid), dim3(256), 0, c->stream, (const K *)keys, rb.parents, rb.plans, every);
-			} else
-				hipLaunchKernelGGL((direct_hist_kernel<K>), dim3(ns), dim3(1024), 0, c->stream, (const K *)keys, rb.stripes, rb.parents, rb.plans);
+			} else {
+				// (the exact check behind a sampled leading-bit skip rides on this pass if it reads every key)
+				hist_checks = unverified && rp.round_keys == n;
+				if (hist_checks) {
+					int rcv = vres_init();
+					if (rcv) return rcv;
+					add_stat(c, "bit_skip_checked_by_histogram", 1);
+				}
+				hipLaunchKernelGGL((direct_hist_kernel<K>), dim3(ns), dim3(1024), 0, c->stream, (const K *)keys, rb.stripes, rb.parents, rb.plans,
+						   hist_checks ? vres : (unsigned long long *)nullptr);
+			}
 			hipLaunchKernelGGL((direct_plan_kernel<B>), dim3(np), dim3(256), 0, c->stream, rb.parents, rb.plans, ctr);
 			phase_mark(c, np == 1 ? "A sample" : "A histogram");
 			// The plan's verdict (Counters::direct_uneven: some parent's children are too unequal, or its keys come in
@@ -856,9 +902,24 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 		if (ahead)
 			HIPCHK(c, hipMemcpyAsync((char *)c->pinned + kSegOff, rb.next_parents, ahead * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+		static_assert(sizeof(Counters) + 2 * sizeof(unsigned long long) <= kSegOff, "counters and the OR/AND words share the head of the staging buffer");
+		if (hist_checks)
+			HIPCHK(c, hipMemcpyAsync((char *)c->pinned + kSegOff - 2 * sizeof(unsigned long long), vres, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(&hc, c->pinned, sizeof hc);
 		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations", round, hc.errors);
+		if (hist_checks) {
+			const unsigned long long *h = (const unsigned long long *)((char *)c->pinned + kSegOff - 2 * sizeof(unsigned long long));
+			const uint64_t exact_vary = h[0] ^ h[1];
+			if (exact_vary & claimed_const) { // some key differs in a bit the sample found constant: all over again, on every varying bit
+				int rcs = start_over(exact_vary);
+				if (rcs) return rcs;
+				round = 0;
+				phase_mark(c, "readback");
+				continue;
+			}
+			unverified = false;
+		}
 		const bool direct = tried_direct && (hc.direct_uneven == 0 || c->direct_mode == 2);
 		if (direct) add_stat(c, "direct_rounds", 1);
 		prev_direct = direct;
@@ -898,6 +959,18 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		}
 		phase_mark(c, "readback");
 		++round;
+	}
+	if (unverified) { // no round's histogram pass carried the check: a pass of its own, before any leaf runs
+		uint64_t vary = 0;
+		int rc = run_vary(1, &vary);
+		if (rc) return rc;
+		phase_mark(c, "bit skip");
+		if (vary & claimed_const) {
+			if ((rc = start_over(vary))) return rc;
+			again = true;
+		} else
+			unverified = false;
+	}
 	}
 
 	// ---- leaves, stage 1: one unstable counting pass over all remaining bits (one workgroup per segment)

@@ -252,6 +252,43 @@ def test_bit_skip_sees_every_key(ctx, n, where):
     assert (host(t) == np.sort(k64)).all()
 
 
+@pytest.mark.parametrize("outlier", [False, True])
+@pytest.mark.parametrize("n,opts,path", [((1 << 26) + 3, {}, "histogram"), ((1 << 24) + 7, {"direct_min": 1 << 20}, "own pass")])
+def test_sampled_bit_skip_is_verified(n, opts, path, outlier):
+    """Big inputs skip leading bits on the word of a sample and check it exactly later -- on the second round's
+    histogram pass if that reads every key, else in a pass of its own before the leaves.  One key that differs in a
+    skipped bit, at a position the sample does not visit, must make the sort start over on all varying bits."""
+    from inplacemsdradixsort_amd import MsdContext
+    c = MsdContext(0)
+    try:
+        for k_, v_ in opts.items():
+            c.set_option(k_, v_)
+        k = O.gen_uniform_u32(n, seed=n) & np.uint32(0x00FFFFFF)       # 8 constant leading bits
+        if outlier:
+            k[12345] |= np.uint32(1 << 29)
+        t = dev(k)
+        c.sort_u32(t)
+        st = c.stats()
+        assert (host(t) == np.sort(k)).all()
+        assert st.get("direct_rounds", 0) >= 1, st
+        if outlier:
+            assert st.get("bit_skip_restarts", 0) == 1 and st.get("skipped_bits", 0) == 2, (path, st)
+        else:
+            assert st.get("bit_skip_restarts", 0) == 0 and st.get("skipped_bits", 0) == 8, (path, st)
+        k64 = k.astype(np.uint64) | (np.uint64(0x7B) << np.uint64(40))   # u64 keys and tuples: 23 constant leading bits
+        if outlier:
+            k64[777] ^= np.uint64(1 << 60)
+        t = dev(k64)
+        r = dev(k64 ^ np.uint64(0xFFFF))
+        c.sort_pairs_u64(t, r)
+        st = c.stats()
+        assert (host(t) == np.sort(k64)).all() and (host(r) == (host(t) ^ np.uint64(0xFFFF))).all()
+        assert st.get("bit_skip_restarts", 0) == (1 if outlier else 0), (path, st)
+        assert st.get("bit_skip_checked_by_histogram", 0) == (1 if path == "histogram" else 0), (path, st)
+    finally:
+        c.close()
+
+
 def test_misaligned_pointer_is_rejected(ctx):
     from inplacemsdradixsort_amd import MsdError
     t = dev(O.gen_uniform_u32(1000))
