@@ -258,9 +258,12 @@ def main():
     # The arrived runs (per source rank, that source's buckets of this rank's range) are gathered bucket-major into a
     # work buffer and sorted there as 256 / N segments on the remaining 24 bits: the local sort does not repeat the
     # top-digit pass.  Two receive buffers (one being filled, one being gathered from), one work buffer per step kept.
+    # (8 ranks: the arrived keys are sorted where they are, on 29 bits -- measured faster there, dist.ShardedSorter; the
+    # outputs then stay in the receive buffers, one per step kept)
     nrecv = max(2, min(W + K, 8))
-    recv = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(2)] if N > 1 else None
-    work = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(nrecv)] if N > 1 else None
+    gathered = 1 < N <= 4
+    recv = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(2 if gathered else nrecv)] if N > 1 else None
+    work = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(nrecv)] if gathered else None
 
     from inplacemsdradixsort_amd.dist import ShardedSorter
     sorter = ShardedSorter(ctx, dist, N, recv, work_bufs=work) if N > 1 else None
@@ -420,7 +423,7 @@ def main():
         "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic" + (" (REHEARSAL: gloo via host memory, all ranks on one GPU)" if rehearsal else ""),
         "config": {"workload": f"2^{args.logn} {cfg['title']} per GPU, in-place MSD radix sort, 8-bit digits"
-                               + (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local sort; the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N > 1 else ""),
+                               + (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local sort" + (f"; the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N <= 4 else f"; the arrived keys are sorted on {32 - N.bit_length() + 1} bits)") if N > 1 else ""),
                    "config_id": args.config, "elements_per_gpu": n, "passes": cfg["passes_note"],
                    "verified": bool(verified), "steps_verified": steps_verified,
                    "workspace_bytes": ctx.workspace_bytes},

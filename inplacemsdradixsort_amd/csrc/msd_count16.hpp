@@ -1,5 +1,6 @@
-// msd_count16.hpp -- the one-pass counting leaf for the case the planner aims at: u32 keys, 16 open bits,
-// a segment that fits the registers of one 512-thread workgroup (included by msd_device.hpp).
+// msd_count16.hpp -- the one-pass counting leaf for the case the planner aims at: u32 keys, 16 open bits (or a few
+// less: the values are then spread over the 2^16 counters by a shift), a segment that fits the registers of one
+// 512-thread workgroup (included by msd_device.hpp).
 //
 // Same algorithm as count_place_kernel (2^16 byte counters in LDS, the fetch-add's return value is the key's
 // rank among equal keys, place = base[owner of the value] + prefix[value] + rank, keys are re-generated as
@@ -29,6 +30,7 @@ constexpr int kC16Th = MSD_C16_TH;
 constexpr int kC16Vec = 4096 / kC16Th;                       // 16-byte vectors per thread: TH * NV * 4 = 16384 elements
 constexpr int kC16Tail = 1024 / kC16Th;                      // + scalar elements per thread behind them
 constexpr uint32_t kC16Cap = kC16Th * (kC16Vec * 4 + kC16Tail); // 17408 elements on the 16-byte grid
+constexpr uint32_t kC16MinBits = 9;                          // fewer open bits: more than 255 copies per value are the rule (byte counters)
 constexpr uint32_t kC16Words = 16384;                        // counter words (4 byte counters each)
 constexpr uint32_t kC16CwWords = kC16Words + (kC16Words >> 6) * 4; // with 4 words of padding per 64
 static_assert(kC16CwWords == kC16Cap, "counters and output buffer share one LDS area");
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 		const uint32_t *base = keys + (g.start - off);
 		const uint64_t tot = g.count + off;
 		// (the last vector of the array's last segment may reach beyond the array: such a segment is not taken)
-		const bool take = g.bits == 16 && tot <= (uint64_t)kC16Cap && ((g.start - off + tot + 3) & ~3ull) <= n_total;
+		const bool take = g.bits >= kC16MinBits && g.bits <= 16 && tot <= (uint64_t)kC16Cap && ((g.start - off + tot + 3) & ~3ull) <= n_total;
 		const uint32_t totc = take ? (uint32_t)tot : 1u;
 		const uint32_t lastv = (totc - 1u) >> 2;
 #pragma unroll
@@ -95,7 +97,8 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 	for (;;) {
 		const uint32_t off = (uint32_t)(sg.start & 3u);
 		const uint32_t tot = (uint32_t)min(sg.count + off, (uint64_t)0xFFFFFFFFu), n = tot - off;
-		const bool fits = sg.bits == 16 && sg.count + off <= (uint64_t)kC16Cap && ((sg.start + sg.count + 3) & ~3ull) <= n_total;
+		const bool fits = sg.bits >= kC16MinBits && sg.bits <= 16 && sg.count + off <= (uint64_t)kC16Cap && ((sg.start + sg.count + 3) & ~3ull) <= n_total;
+		const uint32_t vsh = 16u - (fits ? sg.bits : 16u); // a value of b < 16 bits is counted as value << (16 - b): every thread's counters get their share
 		uint32_t *segb = keys + (sg.start - off); // 16-byte aligned
 		MSD_STAMP(9);
 		MSD_STAMP_TICK(11);
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 			wtot[13] -= 1;
 			*crowded = 0;
 			const uint32_t k0 = off == 0 ? rk[0] : off == 1 ? rk[1] : off == 2 ? rk[2] : rk[3]; // first key
-			*hi_l = k0 & 0xFFFF0000u; // common prefix of the whole segment
+			*hi_l = k0 & ~((1u << sg.bits) - 1u); // common prefix of the whole segment
 		}
 		MSD_STAMP(0); // clear
 		__syncthreads();
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 					const int u = u0 + i;
 					if (u < NK) {
 						const uint32_t el = u < NV * 4 ? (uint32_t)((u / 4) * TH * 4) + tid * 4 + (u % 4) : (uint32_t)(NV * TH * 4 + (u - NV * 4) * TH) + tid;
-						const uint32_t val = rk[u] & 0xFFFFu;
+						const uint32_t val = (rk[u] << vsh) & 0xFFFFu; // (fewer than 16 open bits: spread over the counters, order kept)
 						const bool in = el >= off && el < tot;
 						const uint32_t a = in ? c16_at(val >> 2) : (uint32_t)(junkc - cw) + lane; // word index from cw
 						old[i] = atomicAdd(cw + a, 1u << ((val & 3u) * 8u));
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 #pragma unroll
 			for (int u = 0; u < NK; ++u) {
 				uint32_t *o = (rk[u] >> 31) ? junko + lane : out + ((rk[u] >> 16) & 0x7FFFu);
-				*o = hi | (rk[u] & 0xFFFFu);
+				*o = hi | ((rk[u] & 0xFFFFu) >> vsh);
 			}
 			__syncthreads();
 			MSD_STAMP(8); // output into LDS

@@ -155,7 +155,7 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
         engine.sort_u32(keys)
         return keys
     counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
-    if work is None:
+    if work is None or world > 4:                                # (8 ranks and more: see ShardedSorter)
         send = counts.view(world, 256 // world).sum(dim=1)       # keys per destination rank
         send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
         out = recv[:int(sum(got_l))]
@@ -238,7 +238,10 @@ class ShardedSorter:
         # work buffers: the arrived runs are gathered bucket-major into one of them and sorted there as segments on
         # 24 bits (the local sort does not repeat the top-digit pass); collect() then returns a view of a WORK buffer,
         # overwritten len(work_bufs) collects later.  Without them the keys are sorted where they arrived.
-        self.work = list(work_bufs) if work_bufs else []
+        # (8 ranks and more: the 32 buckets of a rank hold 2^25 keys each at 2^30 keys per rank, one more 8-bit round leaves
+        # 2^17-key segments, beyond the fast counting leaf -- sorting the arrived keys on 29 bits measures faster: 8.5 against
+        # 1.6 + 9.7 ms, tools/multigpu_local_work.py; 2 and 4 ranks: 9.2 and 8.9 against 13.0 and 12.5 ms)
+        self.work = list(work_bufs) if work_bufs and world <= 4 else []
         self._wslot = 0
         self._slot = 0
         self._pending = []
