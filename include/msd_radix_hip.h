@@ -186,7 +186,7 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  *   top-digit buckets are about equally big writes its blocks straight into the bucket's
  *   estimated region and permutes only the misplaced ones; 2 = the same without the sample test.
  *   Rounds after the first follow (from exact per-parent digit counts) if the first round did.
- * "direct_min": smallest round (elements) direct placement is tried on (default 2^26).
+ * "direct_min": smallest round (elements) direct placement is tried on (default 2^22).
  * "direct_min_parent": rounds after the first: smallest parent segment (default 2^17).
  * "direct_kernel": accepted and ignored (round 1's first version of the direct kernel is gone;
  *   profiles/r02_sq_counters.json and r02_stamps_classify_direct_before.json keep its measurements).

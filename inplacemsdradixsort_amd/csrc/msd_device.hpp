@@ -796,7 +796,10 @@ __global__ __launch_bounds__(256) void direct_plan_kernel(const Parent *__restri
 	__syncthreads();
 	// (equal neighbours: 1/256 of the pairs on random keys; an eighth of them means runs)
 	const bool runs = (uint64_t)plan->adj_same * 8u > plan->adj_seen;
-	if (d == 0 && (runs || !(s_mn > 0 && (double)s_mx <= 1.25 * (double)s_mn))) atomicAdd(&ctr->direct_uneven, 1u);
+#ifndef MSD_UNEVEN_PCT // (overridable for experiments)
+#define MSD_UNEVEN_PCT 125
+#endif
+	if (d == 0 && (runs || !(s_mn > 0 && (double)s_mx * 100.0 <= (double)MSD_UNEVEN_PCT * (double)s_mn))) atomicAdd(&ctr->direct_uneven, 1u);
 }
 
 // The `need` lanes with the smallest 10-bit value among the eligible ones (ties: lower lane first).

@@ -1,6 +1,6 @@
 """GPU parity of the first round's direct block placement.
 
-By default the path is only tried on inputs of 2^26 elements and more whose sampled top-digit
+By default the path is only tried on inputs of 2^22 elements and more whose sampled top-digit
 buckets are about equally big; here `direct_min` is lowered so that it runs at sizes numpy
 sorts in a moment, and `direct_mode` 2 drops the sample test so that it also meets inputs it
 is not meant for (skew, few distinct values, sorted runs) -- slow there, but still exact.
