@@ -12,8 +12,11 @@ packs the send side, one RCCL all-to-all exchanges key ranges, each rank sorts
 what it received; value = all ranks' keys / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  roofline     -- dominant kernel: algorithmic bytes / HIP-event time vs 8 TB/s
-  cpu_baseline -- the reference's single-thread core (oracle/_ref) on a bounded sample
+  roofline      -- dominant kernel: algorithmic bytes / HIP-event time vs 8 TB/s (N > 1: the whole local sort per GPU,
+                   the exchange's bytes and time beside it)
+  cpu_baseline  -- the reference's own 64-thread sort() (oracle/_ref) on 2^30 (or 2^28) tuples on this host, verified,
+                   with its single-thread core on 2^27 keys beside it (rank 0; a reported baseline, not the target)
+  other_configs -- (default single-GPU run) configs c3, c5a, c5b: three verified steps each, after the headline loop
 """
 from __future__ import annotations
 
@@ -87,6 +90,8 @@ def parse():
                     help="gloo: REHEARSAL of the N > 1 path with all ranks on cuda:0 and the collectives staged through "
                          "host memory (RCCL cannot run several ranks on one device); its numbers mean nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="headline only (the default c2 run also times c3, c5a, c5b)")
+    ap.add_argument("--scheme", choices=["fine", "coarse"], default=None, help="N > 1: force the sharding scheme (dist.use_fine)")
     ap.add_argument("--cpu-logn", type=int, default=None, help="log2 tuples for the reference's 64-thread sort() "
                     "(default: 30 when the host has the memory for it, else 28)")
     ap.add_argument("--cpu-logn-1t", type=int, default=27, help="log2 keys for the single-thread core")
@@ -192,12 +197,167 @@ def git_sha() -> str:
         return "?"
 
 
+def torch_check(torch, t, rids=None, chunk: int = 1 << 26):
+    """Independent of the library's own check kernel: (order violations, key sum mod 2^64[, key != rid]) of a tensor of
+    u32 / u64 bit patterns, by chunked torch reductions (neighbours compared as unsigned, chunk boundaries included)."""
+    n = t.numel()
+    viol, total, mism = 0, 0, 0
+    prev_last = None
+    for a in range(0, n, chunk):
+        c = t[a:a + chunk]
+        if t.element_size() == 4:
+            u = c.to(torch.int64) & 0xFFFFFFFF                 # unsigned value
+            total += int(u.sum().item())
+        else:
+            u = c ^ (-(1 << 63))                                # unsigned order as signed order
+            total += int(c.sum().item())                        # (wraps like the device sum)
+        viol += int((u[1:] < u[:-1]).sum().item())
+        if prev_last is not None and int(u[0].item()) < prev_last:
+            viol += 1
+        prev_last = int(u[-1].item())
+        if rids is not None:
+            mism += int((c != rids[a:a + chunk]).sum().item())
+    return viol, total & ((1 << 64) - 1), mism
+
+
+def load_pmc(config_id: str):
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json" if config_id == "c2" else f"pmc_traffic_{config_id}.json")
+    if os.path.exists(pmc_file):
+        try:
+            return json.load(open(pmc_file)), pmc_file
+        except Exception:
+            pass
+    return None, pmc_file
+
+
+def profile_one_sort(ctx, torch, cfg, config_id, n, gen, sort, t, r):
+    """Per-kernel HIP-event timing of one more sort (profiling adds event records, so it is separate from the timed
+    loop) -> the `roofline` object for the dominant kernel, and the bytes one whole sort really moves (committed PMC)."""
+    gen(t, 77)
+    if r is not None:
+        r.copy_(t)
+    ctx.set_profiling(True)
+    sort(t, r)
+    torch.cuda.synchronize()
+    ctx.set_profiling(False)
+    ph = dict(ctx.phases())
+    st = ctx.stats()
+    rounds = st.get("rounds", 0)
+    direct = st.get("direct_rounds", 0)
+    KA = kernel_algo(cfg)
+    rnd_bytes = cfg["key"] + 2 * (cfg["key"] + cfg["val"])
+    dom = max((p for p in ph if p in KA), key=lambda p: ph[p], default=None)
+    pmc, pmc_file = load_pmc(config_id)
+    roofline, real = None, None
+    if dom:
+        name, per_elem = KA[dom]
+        if per_elem is None:  # leaves: the digit passes the partition rounds left over
+            launches, algo = 1, n * rnd_bytes * max(0, cfg["passes"] - rounds)
+        else:
+            launches = {"A classify direct": max(1, direct), "A histogram": max(1, direct - 1),
+                        "A classify": max(1, rounds - direct)}.get(dom, max(1, rounds))
+            algo = n * per_elem
+        avg_us = ph[dom] / launches
+        ach = algo / (avg_us * 1e-6) / 1e9
+        rec = (pmc or {}).get(name)
+        if rec is None and pmc:  # extra template arguments in the profiler's name: classify_kernel<u32, false>
+            rec = next((v for k, v in pmc.items() if k.startswith(name[:-1] + ",")), None)
+        traffic = (rec or {}).get("hbm_bytes_per_launch")
+        sha = (pmc or {}).get("__meta__", {}).get("git_sha") or git_sha()
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    # the PMC bytes are a committed measurement of the same kernel and workload (separate rocprofv3
+                    # --pmc passes, FETCH_SIZE x2 as the guide prescribes), not collected inside this run
+                    "traffic_source": None if traffic is None else f"{os.path.relpath(pmc_file, ROOT)} @ {sha} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, committed)",
+                    "moved_GBps": None if not traffic else round(traffic / (avg_us * 1e-6) / 1e9, 1),
+                    "avg_launch_us": round(avg_us, 1), "launches_per_sort": launches,
+                    "algorithmic_bytes_per_launch": int(algo),
+                    "measured_ceilings_GBps": CEILINGS_GBS,
+                    "phases_us": {k: round(v, 1) for k, v in ph.items()}}
+    if pmc:  # bytes one whole sort really moves, from the same committed PMC profile
+        real = pmc.get("__per_sort__", {}).get("hbm_bytes")
+    return roofline, real
+
+
+def whole_sort_block(cfg, n, sec_per_step, real, copy_gbps=None):
+    bpe = algo_bytes_per_elem(cfg)
+    whole = n * bpe / sec_per_step / 1e9
+    return {"algorithmic_GBps_per_gpu": round(whole, 1), "algorithmic_frac_of_peak": round(whole / HBM_PEAK_GBS, 4),
+            "algorithmic_bytes_per_element": bpe,
+            "note": "the algorithmic figure is SURVEY.md section 8d's fixed 3-touches-per-8-bit-pass model; the sort moves fewer "
+                    "bytes (real_*), so the algorithmic rate is a speed-up over that model, not achieved bandwidth",
+            "real_bytes_per_element": None if not real else round(real / n, 2),
+            "real_GBps": None if not real else round(real / sec_per_step / 1e9, 1),
+            "real_frac_of_peak": None if not real else round(real / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
+            "device_copy_GBps_same_run": None if copy_gbps is None else round(copy_gbps, 1)}
+
+
+def make_workload(ctx, torch, config_id, rank, n):
+    cfg = CONFIGS[config_id]
+    pairs = cfg["val"] > 0
+
+    def gen(t, s):
+        if config_id == "c2":
+            ctx.gen_uniform_u32(t, seed=0x5EED0001 + 1000003 * s, first=rank * n)  # C4: global index over all shards
+        elif config_id == "c3":
+            ctx.gen_zipf_u32(t, seed=0x5EED0003 + 1000003 * s, first=rank * n)
+        else:
+            ctx.gen_uniform_u64(t, seed=0x5EED0005 + 1000003 * s, first=rank * n, shift_right=32 if config_id == "c5b" else 0)
+
+    def sort(t, r=None):
+        if cfg["dtype"] == "u32":
+            ctx.sort_u32(t)
+        elif pairs:
+            ctx.sort_pairs_u64(t, r)
+        else:
+            ctx.sort_u64(t)
+
+    return cfg, pairs, (torch.int32 if cfg["key"] == 4 else torch.int64), gen, sort
+
+
+def run_other_config(ctx, torch, config_id, logn, steps=3, warmup=1):
+    """One more single-GPU config inside the default run: `steps` timed sorts of fresh inputs (one
+    buffer, regenerated before every step outside the clock), every one verified by the library's check AND the
+    independent torch reduction; then one profiled sort for the dominant kernel."""
+    n = 1 << logn
+    cfg, pairs, tdt, gen, sort = make_workload(ctx, torch, config_id, 0, n)
+    t = torch.empty(n, dtype=tdt, device="cuda")
+    r = torch.empty(n, dtype=tdt, device="cuda") if pairs else None
+    ctx.reserve(n + n // 8, cfg["key"], cfg["val"])
+    ms, verified = [], True
+    for s in range(warmup + steps):
+        gen(t, 200 + s)
+        if pairs:
+            r.copy_(t)                      # rid = key, the reference's check(..., same=1) convention
+        c0 = ctx.check(t)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sort(t, r)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if s >= warmup:
+            ms.append(dt * 1e3)
+            v, s_, x_ = ctx.check(t, r) if pairs else ctx.check(t)
+            tv, ts, tm = torch_check(torch, t, r)
+            verified &= (v == 0 and s_ == c0[1] and x_ == c0[2] and tv == 0 and ts == c0[1] and tm == 0)
+    roofline, real = profile_one_sort(ctx, torch, cfg, config_id, n, gen, sort, t, r)
+    sec = sum(ms) / len(ms) * 1e-3
+    unit = "Gtuples/s" if pairs else "Gkeys/s"
+    out = {"workload": f"2^{logn} {cfg['title']}", "ms_per_step": round(sec * 1e3, 3), "steps": steps, "ms_each": [round(x, 3) for x in ms],
+           "value": round(n / sec / 1e9, 3), "unit": unit, "dtype": cfg["dtype"], "verified": bool(verified),
+           "whole_sort": whole_sort_block(cfg, n, sec, real), "roofline": roofline}
+    out["whole_sort"].pop("note", None)
+    del t, r
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
-    cfg = CONFIGS[args.config]
     import torch
     import torch.distributed as dist
     from inplacemsdradixsort_amd import MsdContext
+    from inplacemsdradixsort_amd.dist import ShardedSorter, use_fine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -205,7 +365,7 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     N = world
-    if N > 1 and cfg["dtype"] != "u32":
+    if N > 1 and CONFIGS[args.config]["dtype"] != "u32":
         raise SystemExit("the multi-GPU path shards u32 keys (configs c2 / c3)")
     rehearsal = N > 1 and args.backend == "gloo"
     if rehearsal:
@@ -224,24 +384,7 @@ def main():
     ctx.use_torch_stream()
     n = 1 << args.logn
     W, K = args.warmup, args.steps
-    pairs = cfg["val"] > 0
-    tdt = torch.int32 if cfg["key"] == 4 else torch.int64
-
-    def gen(t, s):
-        if args.config == "c2":
-            ctx.gen_uniform_u32(t, seed=0x5EED0001 + 1000003 * s, first=rank * n)  # C4: global index over all shards
-        elif args.config == "c3":
-            ctx.gen_zipf_u32(t, seed=0x5EED0003 + 1000003 * s, first=rank * n)
-        else:
-            ctx.gen_uniform_u64(t, seed=0x5EED0005 + 1000003 * s, first=rank * n, shift_right=32 if args.config == "c5b" else 0)
-
-    def sort(t, r=None):
-        if cfg["dtype"] == "u32":
-            ctx.sort_u32(t)
-        elif pairs:
-            ctx.sort_pairs_u64(t, r)
-        else:
-            ctx.sort_u64(t)
+    cfg, pairs, tdt, gen, sort = make_workload(ctx, torch, args.config, rank, n)
 
     # ---- inputs for every step, resident before the clock starts
     bufs, rids = [], []
@@ -253,20 +396,23 @@ def main():
     ctx.reserve(n + n // 8, cfg["key"], cfg["val"])
     checks0 = [ctx.check(t) for t in bufs]          # (violations, sum, xor) of every input
     # N > 1: receive buffers with 12.5 % slack (the reference's fudge); the exchange of step s runs (RCCL stream, xGMI)
-    # while step s-1 is sorted locally -- inplacemsdradixsort_amd.dist.ShardedSorter.  One buffer per step (up to 8), so
-    # that the outputs of the last steps are still there when the clock has stopped and can all be verified.
-    # The arrived runs (per source rank, that source's buckets of this rank's range) are gathered bucket-major into a
-    # work buffer and sorted there as 256 / N segments on the remaining 24 bits: the local sort does not repeat the
-    # top-digit pass.  Two receive buffers (one being filled, one being gathered from), one work buffer per step kept.
-    # (8 ranks: the arrived keys are sorted where they are, on 29 bits -- measured faster there, dist.ShardedSorter; the
-    # outputs then stay in the receive buffers, one per step kept)
-    nrecv = max(2, min(W + K, 8))
-    gathered = 1 < N <= 4
-    recv = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(2 if gathered else nrecv)] if N > 1 else None
-    work = [torch.empty(n + n // 8, dtype=torch.int32, device="cuda") for _ in range(nrecv)] if gathered else None
-
-    from inplacemsdradixsort_amd.dist import ShardedSorter
-    sorter = ShardedSorter(ctx, dist, N, recv, work_bufs=work) if N > 1 else None
+    # while step s-1 is finished locally -- inplacemsdradixsort_amd.dist.ShardedSorter.
+    # Fine scheme (shards of >= 2^27 keys): the shard is ordered by its top 16 bits before the exchange, the counting leaf
+    # reads what arrived in one of TWO receive buffers (one being filled, one being read) and writes a work buffer -- one
+    # per timed step when the memory allows, so that EVERY timed step's output is still there when the clock has stopped
+    # and is verified.  Coarse scheme (small shards): round 2's path (gather + segmented sort at <= 4 ranks, sort on
+    # 32 - log2 N bits where the keys arrived at 8).
+    fine = N > 1 and use_fine(n, N, True, args.scheme)
+    cap = n + n // 8
+    nkeep = 0
+    recv = work = None
+    if N > 1:
+        free_b, _ = torch.cuda.mem_get_info()
+        nkeep = int(max(2, min(K, 24, (free_b - (6 << 30)) // (cap * 4) - 2)))
+        gathered = fine or N <= 4
+        recv = [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(2 if gathered else nkeep)]
+        work = [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(nkeep)] if gathered else None
+    sorter = ShardedSorter(ctx, dist, N, recv, work_bufs=work, scheme=args.scheme) if N > 1 else None
 
     def run_steps(lo, hi):
         if N == 1:
@@ -299,21 +445,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- verify the timed steps' outputs (outside the clock)
+    # ---- verify the timed steps' outputs (outside the clock): the library's check kernel AND an independent torch reduction
     verified, steps_verified = True, 0
     if N == 1:
         for i, o in outs:
             v, s_, x_ = ctx.check(o, rids[i]) if pairs else ctx.check(o)   # pairs: order and key == rid
-            verified &= (v == 0 and s_ == checks0[i][1] and x_ == checks0[i][2])
+            tv, ts, tm = torch_check(torch, o, rids[i] if pairs else None)
+            verified &= (v == 0 and s_ == checks0[i][1] and x_ == checks0[i][2] and tv == 0 and ts == checks0[i][1] and tm == 0)
             steps_verified += 1
     else:
-        # Every output still in a receive buffer (the last nrecv steps): sorted on its rank, key sum and xor of all
-        # ranks' outputs == those of all ranks' inputs, rank r's keys carry top bits r and follow rank r-1's
-        # (what the reference's check() verifies across its numa arrays, src/msb_64.c:2432-2505).
+        # Every output still in a buffer (all timed steps when the memory allowed one work buffer each, else the last
+        # nkeep): sorted on its rank (two independent checks), key sum and xor of all ranks' outputs == those of all
+        # ranks' inputs, rank r's keys carry top bits r and follow rank r-1's (what the reference's check() verifies
+        # across its numa arrays, src/msb_64.c:2432-2505).
         lg = N.bit_length() - 1
         M64 = (1 << 64) - 1
-        for i, o in outs[-nrecv:]:
+        for i, o in outs[-nkeep:]:
             v, s_, x_ = ctx.check(o)
+            tv, ts, _ = torch_check(torch, o)
+            v += tv + (0 if ts == s_ else 1)
             cnt = o.numel()
             lo_k = (int(o[0].item()) & 0xFFFFFFFF) if cnt else -1
             hi_k = (int(o[-1].item()) & 0xFFFFFFFF) if cnt else -1
@@ -343,63 +493,12 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verified = bool(flag.item())
 
-    # ---- per-kernel HIP-event timing of one more step (profiling adds event records, so it is separate)
-    roofline, real = None, None
+    roofline, real, copy_gbps, multi = None, None, None, None
     if N == 1:
-        t = bufs[0]
-        gen(t, 77)
-        r = t.clone() if pairs else None
-        ctx.set_profiling(True)
-        sort(t, r)
-        torch.cuda.synchronize()
-        ctx.set_profiling(False)
+        r = bufs[0].clone() if pairs else None
+        roofline, real = profile_one_sort(ctx, torch, cfg, args.config, n, gen, sort, bufs[0], r)
         del r
-        ph = dict(ctx.phases())
-        st = ctx.stats()
-        rounds = st.get("rounds", 0)
-        direct = st.get("direct_rounds", 0)
-        KA = kernel_algo(cfg)
-        rnd_bytes = cfg["key"] + 2 * (cfg["key"] + cfg["val"])
-        dom = max((p for p in ph if p in KA), key=lambda p: ph[p], default=None)
-        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json" if args.config == "c2" else f"pmc_traffic_{args.config}.json")
-        pmc = None
-        if os.path.exists(pmc_file):
-            try:
-                pmc = json.load(open(pmc_file))
-            except Exception:
-                pmc = None
-        if dom:
-            name, per_elem = KA[dom]
-            if per_elem is None:  # leaves: the digit passes the partition rounds left over
-                launches, algo = 1, n * rnd_bytes * max(0, cfg["passes"] - rounds)
-            else:
-                launches = {"A classify direct": max(1, direct), "A histogram": max(1, direct - 1),
-                            "A classify": max(1, rounds - direct)}.get(dom, max(1, rounds))
-                algo = n * per_elem
-            avg_us = ph[dom] / launches
-            ach = algo / (avg_us * 1e-6) / 1e9
-            rec = (pmc or {}).get(name)
-            if rec is None and pmc:  # extra template arguments in the profiler's name: classify_kernel<u32, false>
-                rec = next((v for k, v in pmc.items() if k.startswith(name[:-1] + ",")), None)
-            traffic = (rec or {}).get("hbm_bytes_per_launch")
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        # the PMC bytes are a committed measurement of the same kernel and workload (separate rocprofv3
-                        # --pmc passes, FETCH_SIZE x2 as the guide prescribes), not collected inside this run
-                        "traffic_source": None if traffic is None else f"{os.path.relpath(pmc_file, ROOT)} @ {git_sha()} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command, committed)",
-                        "moved_GBps": None if not traffic else round(traffic / (avg_us * 1e-6) / 1e9, 1),
-                        "avg_launch_us": round(avg_us, 1), "launches_per_sort": launches,
-                        "algorithmic_bytes_per_launch": int(algo),
-                        "measured_ceilings_GBps": CEILINGS_GBS,
-                        "phases_us": {k: round(v, 1) for k, v in ph.items()}}
-        if pmc:  # bytes one whole sort really moves, from the same committed PMC profile
-            tot = pmc.get("__per_sort__", {}).get("hbm_bytes")
-            if tot:
-                real = tot
-
-    # ---- achievable copy rate on this device, same run (second denominator)
-    copy_gbps = None
-    if N == 1:
+        # ---- achievable copy rate on this device, same run (second denominator)
         a, b = bufs[0], bufs[1] if len(bufs) > 1 else torch.empty_like(bufs[0])
         b.copy_(a)
         torch.cuda.synchronize()
@@ -410,37 +509,94 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         copy_gbps = 5 * 2 * a.numel() * a.element_size() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    else:
+        # ---- N > 1: what a step consists of, measured apart after the clock has stopped (3 repetitions, max over ranks):
+        # the local work alone (before + after the exchange, nothing in flight) and the exchange alone.  The timed loop
+        # overlaps them (ms_per_step); their sum is what it would cost without the overlap.
+        def max_over_ranks(ms):
+            x = torch.tensor([ms], dtype=torch.float64, device="cuda")
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            return float(x.item())
+
+        pre_ms, post_ms, xch_ms, xch_bytes = [], [], [], 0
+        for rep in range(3):
+            gen(bufs[0], 300 + rep)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            sorter.submit(bufs[0])                      # pre-exchange pass + count exchange + the all-to-all is started
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            out_view, handle, _ = sorter._pending[0]
+            if handle is not None:
+                handle.wait()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t3 = time.perf_counter()
+            sorter.collect()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            pre_ms.append((t2 - t1) * 1e3)
+            xch_ms.append((t3 - t2) * 1e3)
+            post_ms.append((t4 - t3) * 1e3)
+            xch_bytes = out_view.numel() * 4
+        k_algo = algo_bytes_per_elem(cfg)
+        sec = dt / K
+        multi = {"scheme": "fine (top 16 bits before the exchange, counting leaf over the arrived extents)" if fine else "coarse (top digit before the exchange)",
+                 "local_before_exchange_ms": round(max_over_ranks(min(pre_ms)), 3),
+                 "local_after_exchange_ms": round(max_over_ranks(min(post_ms)), 3),
+                 "exchange_alone_ms": round(max_over_ranks(min(xch_ms)), 3),
+                 "note_before": "includes the count exchange (one all-gather + one small device-to-host copy) and the launch of the all-to-all; "
+                                "the all-to-all then runs alone (not overlapped) and is what exchange_alone_ms times",
+                 "exchange_bytes_received_per_gpu": int(xch_bytes),
+                 "exchange_GBps_per_gpu_alone": round(xch_bytes / (max(min(xch_ms), 1e-6) * 1e-3) / 1e9, 1)}
+        # the `roofline` object of an N > 1 line: the whole per-GPU step against the HBM peak (algorithmic bytes as for one
+        # GPU: the rank sorts 2^logn keys per step whatever their origin); the exchange is reported beside it
+        roofline = {"bound": "hbm", "kernel": "whole per-GPU step (pre-exchange pass + counting leaf; exchange overlapped)",
+                    "achieved": round(n * k_algo / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(n * k_algo / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(n * k_algo), "avg_launch_us": round(sec * 1e6, 1), "multi_gpu": multi}
 
     total = N * n * K
     value = total / dt / 1e9
-    bpe = algo_bytes_per_elem(cfg)
-    whole = n * bpe / (dt / K) / 1e9  # per-GPU algorithmic GB/s
     unit = "Gtuples/s" if pairs else "Gkeys/s"
     headline = "Gkeys/s + achieved HBM GB/s, 2^30 uniform u32 keys, 1/2/4/8 MI355X"
+    if N > 1:
+        how = (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local work; "
+               + ("fine scheme: shard ordered by its top 16 bits before the exchange, one counting pass over the arrived extents after it)" if fine
+                  else (f"the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N <= 4
+                        else f"the arrived keys are sorted on {32 - N.bit_length() + 1} bits)")))
+    else:
+        how = ""
     out = {
         "metric": headline if args.config == "c2" else f"{unit} + achieved HBM GB/s, 2^{args.logn} {cfg['title']}, 1 MI355X",
         "value": round(value, 3), "unit": unit if args.config != "c2" else "Gkeys/s", "n_gpus": N, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic" + (" (REHEARSAL: gloo via host memory, all ranks on one GPU)" if rehearsal else ""),
-        "config": {"workload": f"2^{args.logn} {cfg['title']} per GPU, in-place MSD radix sort, 8-bit digits"
-                               + (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local sort" + (f"; the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N <= 4 else f"; the arrived keys are sorted on {32 - N.bit_length() + 1} bits)") if N > 1 else ""),
+        "config": {"workload": f"2^{args.logn} {cfg['title']} per GPU, in-place MSD radix sort, 8-bit digits" + how,
                    "config_id": args.config, "elements_per_gpu": n, "passes": cfg["passes_note"],
                    "verified": bool(verified), "steps_verified": steps_verified,
+                   "verified_by": "msd_check_* (device) and an independent chunked torch reduction (order, sum" + (", key == rid)" if pairs else ")"),
                    "workspace_bytes": ctx.workspace_bytes},
-        "whole_sort": {"algorithmic_GBps_per_gpu": round(whole, 1), "algorithmic_frac_of_peak": round(whole / HBM_PEAK_GBS, 4),
-                       "algorithmic_bytes_per_element": bpe,
-                       "note": "the algorithmic figure is SURVEY.md section 8d's fixed 3-touches-per-8-bit-pass model; the sort moves fewer "
-                               "bytes (real_*), so the algorithmic rate is a speed-up over that model, not achieved bandwidth",
-                       "real_bytes_per_element": None if not real else round(real / n, 2),
-                       "real_GBps": None if not real else round(real / (dt / K) / 1e9, 1),
-                       "real_frac_of_peak": None if not real else round(real / (dt / K) / 1e9 / HBM_PEAK_GBS, 4),
-                       "device_copy_GBps_same_run": None if copy_gbps is None else round(copy_gbps, 1)},
+        "whole_sort": whole_sort_block(cfg, n, dt / K, real, copy_gbps),
         "roofline": roofline,
     }
+    # ---- the other single-GPU configs in the same record (default run only): headline buffers are freed first
+    if N == 1 and args.config == "c2" and not args.no_other_configs and args.logn == 30:
+        del bufs, rids, outs
+        torch.cuda.empty_cache()
+        others = {}
+        for cid in ("c3", "c5a", "c5b"):
+            try:
+                others[cid] = run_other_config(ctx, torch, cid, args.logn)
+            except Exception as e:  # a failing side config must not take the headline line with it
+                others[cid] = {"error": f"{type(e).__name__}: {e}"}
+        out["other_configs"] = others
     if rank == 0:
-        out["cpu_baseline"] = None if (args.no_cpu_baseline or N > 1) else cpu_baseline(args.cpu_logn, args.cpu_logn_1t)
+        out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_logn, args.cpu_logn_1t)
         print(json.dumps(out), flush=True)
     if N > 1:
+        dist.barrier()            # the other ranks wait for rank 0's CPU baseline
         dist.destroy_process_group()
 
 

@@ -121,6 +121,36 @@ int msd_gather_runs_u32(msd_ctx *ctx, uint32_t *d_dst, const uint32_t *d_src, co
 int msd_gather_runs_u64(msd_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, const uint64_t *src_off,
 			const uint64_t *dst_off, const uint64_t *len, uint32_t nruns);
 
+/* ---- fine-grained sharding: the top digits are sorted BEFORE the exchange, the open bits are counted after it ----
+ * A rank of the multi-GPU sort whose keys are evenly spread orders its shard by the top 16 key bits first (two
+ * direct-placement rounds -- they run at full speed there, whereas what ARRIVES after an exchange is run-structured),
+ * learns the boundaries of its 2^16 buckets, sends every destination rank its range of buckets in ONE all-to-all, and
+ * finishes every bucket it received -- nsrc extents, one per source rank -- with one counting pass that reads the
+ * extents where they arrived and writes the sorted bucket to its place in a second buffer.  The reference's nodes do
+ * the same after their block exchange: whole buckets are sorted locally on the bits that are left
+ * (src/msb_64.c:2200-2255, `bits` :2242; range boundaries from the histograms :1546-1564).
+ *   msd_sort_*_top: like msd_sort_*_bits, but stops once the keys are ordered by key >> begin_bit (keys that agree
+ *     above begin_bit end up adjacent, in any order).  begin_bit = 0 is the full sort.
+ *   msd_bucket_bounds_*: d_bounds[b] = first index i with (d_keys[i] >> shift) >= first + b, b = 0 .. nbuckets
+ *     (nbuckets + 1 uint64 on the device); the keys must be ordered by key >> shift.  Asynchronous.
+ *   msd_merge_buckets_u32: d_counts = nsrc x nbuckets uint64 ON THE DEVICE (row x: the lengths of source x's
+ *     extents, bucket by bucket); source x's extents lie back to back in d_src from element src_base[x] on (HOST
+ *     array of nsrc offsets: where the all-to-all put source x's keys).  Bucket j holds the keys whose bits above
+ *     open_bits equal first_prefix + j; all its keys differ only in their low open_bits <= 16 bits.  The sorted
+ *     buckets are written back to back to d_dst (n_expected = the sum of all counts <= dst_cap elements; the call
+ *     fails with MSD_EINVAL and writes nothing if the counts do not add up to it).  d_src (src_cap elements) and
+ *     d_dst must not overlap.  nsrc <= 8.  Blocks the calling thread until the leaf has run (one small readback:
+ *     buckets it did not take -- longer than 17408 keys, more than 255 copies of one key -- are finished by the
+ *     general leaves, msd_stat "merge_rejected"). */
+int msd_sort_u32_top(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, int end_bit, int begin_bit);
+int msd_sort_u64_top(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, int end_bit, int begin_bit);
+int msd_sort_pairs_u64_top(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n, int end_bit, int begin_bit);
+int msd_bucket_bounds_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, unsigned shift, uint64_t first, uint32_t nbuckets, uint64_t *d_bounds);
+int msd_bucket_bounds_u64(msd_ctx *ctx, const uint64_t *d_keys, uint64_t n, unsigned shift, uint64_t first, uint32_t nbuckets, uint64_t *d_bounds);
+int msd_merge_buckets_u32(msd_ctx *ctx, const uint32_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base,
+			  uint32_t nsrc, uint32_t nbuckets, int open_bits, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap,
+			  uint64_t n_expected);
+
 /* ---- splitter service: sample -> sort (msd_sort_u32) -> delimiters -> range partition ----
  * The reference's front end for skewed keys (src/msb_64.c:1511-1564): a random sample of the
  * UNSORTED data (:1511-1521, index = mulhi(rand64, n); here a counter-based generator, seed + i),

@@ -87,6 +87,36 @@ class MsdContext:
             raise MsdError("keys and rids differ in length")
         self._ok(self._L.msd_sort_pairs_u64_bits(self._h, self._ptr(keys, 8), self._ptr(rids, 8), keys.numel(), end_bit))
 
+    # ---- fine-grained sharding (include/msd_radix_hip.h): top digits before the exchange, open bits after it
+    def sort_top(self, keys, begin_bit: int, end_bit: Optional[int] = None, rids=None) -> None:
+        """Orders ``keys`` by ``key >> begin_bit`` only (keys that agree above ``begin_bit`` end up adjacent, in any order)."""
+        eb = keys.element_size() * 8 if end_bit is None else end_bit
+        if rids is not None:
+            self._ok(self._L.msd_sort_pairs_u64_top(self._h, self._ptr(keys, 8), self._ptr(rids, 8), keys.numel(), eb, begin_bit))
+        elif keys.element_size() == 4:
+            self._ok(self._L.msd_sort_u32_top(self._h, self._ptr(keys, 4), keys.numel(), eb, begin_bit))
+        else:
+            self._ok(self._L.msd_sort_u64_top(self._h, self._ptr(keys, 8), keys.numel(), eb, begin_bit))
+
+    def bucket_bounds(self, keys, shift: int, nbuckets: int, first: int = 0):
+        """int64[nbuckets + 1] on the device: bounds[b] = first index whose ``key >> shift`` is >= first + b
+        (``keys`` ordered by ``key >> shift``)."""
+        torch = _torch()
+        out = torch.empty(nbuckets + 1, dtype=torch.int64, device=keys.device)
+        f = self._L.msd_bucket_bounds_u32 if keys.element_size() == 4 else self._L.msd_bucket_bounds_u64
+        self._ok(f(self._h, self._ptr(keys, keys.element_size()), keys.numel(), shift, first, nbuckets, C.c_void_p(out.data_ptr())))
+        return out
+
+    def merge_buckets(self, src, counts, src_base, open_bits: int, first_prefix: int, dst, n_expected: int) -> None:
+        """Finishes the buckets a rank received: ``counts`` = int64[nsrc, nbuckets] on the device (extent lengths per
+        source row and bucket), source x's extents lie back to back in ``src`` from ``src_base[x]`` on; the sorted
+        buckets are written back to back into ``dst``."""
+        nsrc, nb = int(counts.shape[0]), int(counts.shape[1])
+        if len(src_base) != nsrc:
+            raise MsdError("merge_buckets: one base offset per source row")
+        self._ok(self._L.msd_merge_buckets_u32(self._h, self._ptr(src, 4), src.numel(), self._ptr(counts, 8), self._u64arr(src_base),
+                                               nsrc, nb, open_bits, first_prefix, self._ptr(dst, 4), dst.numel(), n_expected))
+
     # ---- building blocks
     def histogram(self, keys, shift: int, radix_bits: int):
         torch = _torch()
@@ -218,7 +248,7 @@ class MsdContext:
         out = {}
         for name in ("rounds", "parents", "stripes", "children", "slots", "holes", "chain_steps",
                      "small_segments", "count_segments", "big_count_segments", "direct_rounds", "regpart_rounds", "skipped_bits", "bit_skip_restarts", "bit_skip_checked_by_histogram",
-                     "workspace_bytes"):
+                     "merge_rejected", "workspace_bytes"):
             v = C.c_uint64()
             if self._L.msd_stat(self._h, name.encode(), C.byref(v)) == 0:
                 out[name] = int(v.value)

@@ -1540,7 +1540,10 @@ __global__ __launch_bounds__(64) void excess_kernel(uint32_t nchildren, ChildArr
 __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__ parents, uint32_t nparents, uint32_t wmax, ChildArrays ca,
 	uint64_t small_max, uint64_t med_max, uint32_t small_cap, uint32_t count_bits, Segment *__restrict__ next_parents,
 	Segment *__restrict__ small, Segment *__restrict__ small_count, Segment *__restrict__ big, uint32_t big_cap,
-	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out, uint32_t count_n)
+	Counters *__restrict__ ctr, uint64_t *__restrict__ count_out, uint32_t count_n,
+	// a sort that stops early (msd_sort_*_top: the keys are to be ordered by key >> stop_bits only): children whose open
+	// bits all lie below stop_bits are done
+	uint32_t stop_bits = 0)
 {
 	__shared__ uint32_t s_n[4], s_base[4], s_max; // lists: 0 small, 1 counting leaf, 2 big counting sort, 3 next parents
 	const uint32_t tid = threadIdx.x;
@@ -1557,7 +1560,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 			const uint32_t ci = pa.child_base + d;
 			const uint64_t c = ca.count[ci];
 			if (count_out && ci < count_n) count_out[ci] = c;
-			if (c > 1 && pa.shift != 0) {
+			if (c > 1 && pa.shift > stop_bits) {
 				s.start = ca.start[ci];
 				s.count = c;
 				s.bits = pa.shift;
@@ -1919,6 +1922,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_walk_kernel(K *__restrict__
 
 } // namespace msd
 #include "msd_count16.hpp"
+#include "msd_merge16.hpp"
 namespace msd {
 
 // ------------------------------------------- counting leaf (keys or tuples)

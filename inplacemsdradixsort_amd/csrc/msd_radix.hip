@@ -54,6 +54,7 @@ struct msd_ctx {
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
+	int merge_leaf = 0;    // msd_merge_buckets_u32: 0 = by bucket size, 1 = merge_place16_kernel, 2 = merge_count_kernel (tests)
 };
 
 static int fail(msd_ctx *c, int code, const char *fmt, ...)
@@ -433,7 +434,11 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		     // ... or, instead of a digit, the key's range among nsplit ascending delimiters (msd_partition_by_splitters_*)
 		     const K *splitters = nullptr, uint32_t nsplit = 0,
 		     // ... or a sort of nseg independent segments [seg_off[i], seg_off[i + 1]) on their low end_bit bits (msd_sort_*_segments)
-		     const uint64_t *seg_off = nullptr, uint32_t nseg = 0)
+		     const uint64_t *seg_off = nullptr, uint32_t nseg = 0,
+		     // ... or of an explicit list of disjoint segments, each with its own number of open bits (internal: what the merge leaf rejected)
+		     const std::vector<Segment> *seg_list = nullptr,
+		     // stop early: the keys are only to be ordered by key >> stop_bits (msd_sort_*_top)
+		     uint32_t stop_bits = 0)
 {
 	using C = Cfg<K, V>;
 	constexpr bool HV = has_val<V>::value;
@@ -459,8 +464,15 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			if (seg_off[i] > seg_off[i + 1] || seg_off[i + 1] > n) return fail(c, MSD_EINVAL, "segments: offsets must ascend and stay within n");
 			if (end_bit > 0 && seg_off[i + 1] - seg_off[i] > 1) cur.push_back({ seg_off[i], seg_off[i + 1] - seg_off[i], (uint32_t)end_bit, 0 });
 		}
-	} else if (end_bit > 0 && n > 1)
+	} else if (seg_list) {
+		for (auto &sg : *seg_list) {
+			if (sg.start + sg.count > n || sg.bits > sizeof(K) * 8) return fail(c, MSD_EINVAL, "segments: a segment lies outside the array");
+			if (sg.bits > 0 && sg.count > 1) cur.push_back(sg);
+		}
+		std::sort(cur.begin(), cur.end(), [](const Segment &a, const Segment &b) { return a.start < b.start; });
+	} else if (end_bit > 0 && n > 1 && (uint32_t)end_bit > stop_bits)
 		cur.push_back({ 0, n, (uint32_t)end_bit, 0 });
+	const bool segmented = nseg != 0 || seg_list != nullptr;
 
 	// ---- buffers that live for the whole call
 	{
@@ -513,7 +525,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 	// still the same multiset.
 	bool unverified = false;
 	uint64_t claimed_const = 0; // bits below end_bit the sample found constant
-	if (!single_pass && !nseg && !cur.empty() && n >= 4096) {
+	if (!single_pass && !segmented && !cur.empty() && n >= 4096) {
 		uint64_t vary = 0;
 		int rc = run_vary(std::max<uint64_t>(1, n / 8192), &vary);
 		if (rc) return rc;
@@ -538,10 +550,11 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			}
 		}
 		phase_mark(c, "bit skip");
+		if (!cur.empty() && cur[0].bits <= stop_bits) cur.clear(); // (a sort that stops above every varying bit)
 	}
 
 	uint32_t nsmall_host = 0, ncount_host = 0, nbig_host = 0;
-	if (nseg && !cur.empty()) {
+	if (segmented && !cur.empty()) {
 		// segments that need no partition round go to the leaf lists at once, by collect_kernel's rules
 		std::vector<Segment> l_small, l_count, l_big, parents;
 		for (auto &sg : cur) {
@@ -580,7 +593,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		cur = parents;
 	}
 	if constexpr (!HV) { // <= 16 open bits from the start (small key range): no partition round at all
-		if (!single_pass && !nseg && !cur.empty() && n > small_max && cur[0].bits <= count_bits && n < 0xFFFF0000ull) {
+		if (!single_pass && !segmented && !cur.empty() && n > small_max && cur[0].bits <= count_bits && n < 0xFFFF0000ull) {
 			HIPCHK(c, hipStreamSynchronize(c->stream));
 			memcpy(c->pinned, &cur[0], sizeof(Segment));
 			HIPCHK(c, hipMemcpyAsync(big, c->pinned, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
@@ -588,7 +601,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			cur.clear();
 		}
 	}
-	if (!single_pass && !nseg && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
+	if (!single_pass && !segmented && !cur.empty() && n <= small_max) { // fits LDS: no partition round at all
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(c->pinned, &cur[0], sizeof(Segment));
 		HIPCHK(c, hipMemcpyAsync(small, c->pinned, sizeof(Segment), hipMemcpyHostToDevice, c->stream));
@@ -608,7 +621,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		set_stat(c, "skipped_bits", (uint64_t)(end_bit - top));
 		add_stat(c, "bit_skip_restarts", 1);
 		cur.clear();
-		if (top > 0) cur.push_back({ 0, n, (uint32_t)top, 0 });
+		if (top > 0 && (uint32_t)top > stop_bits) cur.push_back({ 0, n, (uint32_t)top, 0 });
 		nsmall_host = ncount_host = nbig_host = 0;
 		dev_np = 0;
 		prev_direct = false;
@@ -687,7 +700,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					const uint32_t wmax_rp = regpart_width(kRpCap, 64, small_max); // (the widest digit of the rule)
 					hipLaunchKernelGGL(collect_kernel, dim3((np + (256u >> wmax_rp) - 1) / (256u >> wmax_rp)), dim3(256), 0, c->stream, (const Parent *)d_parents, np, wmax_rp, ca, small_max, small_max,
 							   (uint32_t)std::min<size_t>(c->lists_cap, 0xFFFFFFFFu), count_bits, d_next, small, small_count,
-							   HV ? (Segment *)nullptr : big, big_cap, ctr, (uint64_t *)nullptr, nc);
+							   HV ? (Segment *)nullptr : big, big_cap, ctr, (uint64_t *)nullptr, nc, stop_bits);
 					HIPCHK(c, hipGetLastError());
 					phase_mark(c, "C cleanup");
 					Counters hc;
@@ -886,7 +899,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				   single_pass ? ~0ull : small_max, (HV || single_pass) ? small_max : std::max<uint64_t>(small_max, kCountMedMax),
 				   small_cap, single_pass ? 0u : count_bits,
 				   rb.next_parents, small, small_count, (HV || single_pass) ? (Segment *)nullptr : big, big_cap, ctr,
-				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr, splitters ? nsplit + 1u : nc);
+				   (single_pass && sp_count) ? sp_count : (uint64_t *)nullptr, splitters ? nsplit + 1u : nc, stop_bits);
 		HIPCHK(c, hipGetLastError());
 		phase_mark(c, "C cleanup");
 
@@ -1131,9 +1144,20 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
-		if constexpr (sizeof(K) == 4)
+		if constexpr (sizeof(K) == 4) {
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_place16_kernel),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_place16_kernel<2>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_place16_kernel<4>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_place16_kernel<8>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<true>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
+		}
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_place_kernel<K>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCountLds));
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_walk_kernel<K>),
@@ -1312,6 +1336,142 @@ int msd_partition_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, un
 	if (!c) return MSD_EINVAL;
 	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
 	return sort_impl<uint64_t, uint64_t>(c, k, r, n, 64, true, shift, rb, cnt);
+}
+
+// ---- a sort that stops early: afterwards the keys are ordered by key >> begin_bit (the top-digit passes of a rank of the
+// multi-GPU sort before its exchange; keys that agree above begin_bit may be in any order)
+int msd_sort_u32_top(msd_ctx *c, uint32_t *k, uint64_t n, int end_bit, int begin_bit)
+{
+	if (!c) return MSD_EINVAL;
+	if (begin_bit < 0 || begin_bit > end_bit) return fail(c, MSD_EINVAL, "begin_bit must lie in [0, end_bit]");
+	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, end_bit, false, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, (uint32_t)begin_bit);
+}
+int msd_sort_u64_top(msd_ctx *c, uint64_t *k, uint64_t n, int end_bit, int begin_bit)
+{
+	if (!c) return MSD_EINVAL;
+	if (begin_bit < 0 || begin_bit > end_bit) return fail(c, MSD_EINVAL, "begin_bit must lie in [0, end_bit]");
+	return sort_impl<uint64_t, NoVal>(c, k, nullptr, n, end_bit, false, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, (uint32_t)begin_bit);
+}
+int msd_sort_pairs_u64_top(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, int end_bit, int begin_bit)
+{
+	if (!c) return MSD_EINVAL;
+	if (begin_bit < 0 || begin_bit > end_bit) return fail(c, MSD_EINVAL, "begin_bit must lie in [0, end_bit]");
+	return sort_impl<uint64_t, uint64_t>(c, k, r, n, end_bit, false, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, (uint32_t)begin_bit);
+}
+
+} // extern "C"
+
+template <typename K>
+static int bounds_impl(msd_ctx *c, const K *k, uint64_t n, unsigned shift, uint64_t first, uint32_t nbuckets, uint64_t *bounds)
+{
+	if (!c) return MSD_EINVAL;
+	if (!bounds || (n && !k)) return fail(c, MSD_EINVAL, "bucket_bounds: null pointer");
+	if (shift >= sizeof(K) * 8 || nbuckets == 0 || nbuckets > (1u << 24)) return fail(c, MSD_EINVAL, "bucket_bounds: shift or bucket count out of range");
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL((bucket_bounds_kernel<K>), dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, c->stream, k, n, (uint32_t)shift, first, nbuckets, bounds);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+
+// The counting leaf of a rank after a fine-grained exchange (msd_merge16.hpp): every bucket = nsrc extents in d_src.
+static int merge_impl(msd_ctx *c, const uint32_t *src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
+		      uint32_t nb, int open_bits, uint32_t first_prefix, uint32_t *dst, uint64_t dst_cap, uint64_t n_expected)
+{
+	if (!c) return MSD_EINVAL;
+	if (!src || !dst || !d_counts || !src_base) return fail(c, MSD_EINVAL, "merge_buckets: null pointer");
+	if (nsrc < 1 || nsrc > 8) return fail(c, MSD_EINVAL, "merge_buckets: 1..8 source runs per bucket");
+	if (nb == 0 || nb > (1u << 24)) return fail(c, MSD_EINVAL, "merge_buckets: bucket count out of range");
+	if (open_bits < 1 || open_bits > 16) return fail(c, MSD_EINVAL, "merge_buckets: 1..16 open bits");
+	if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(c, MSD_EINVAL, "merge_buckets: buffers must be 16-byte aligned");
+	if (n_expected > dst_cap) return fail(c, MSD_EINVAL, "merge_buckets: the output buffer is too small");
+	if ((uint64_t)first_prefix + nb > (1ull << (32 - open_bits))) return fail(c, MSD_EINVAL, "merge_buckets: bucket numbers exceed the key's prefix");
+	{ // the buffers must not overlap (the leaf reads extents while other workgroups write finished buckets)
+		const uintptr_t s0 = (uintptr_t)src, s1 = s0 + src_cap * 4, d0 = (uintptr_t)dst, d1 = d0 + dst_cap * 4;
+		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "merge_buckets: source and destination overlap");
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	c->stats.clear();
+	phase_begin(c);
+	if (n_expected == 0) return MSD_OK;
+	Bump sz(nullptr), *bp = &sz;
+	Counters *ctr = nullptr;
+	uint32_t *status = nullptr, *cnt32 = nullptr;
+	uint64_t *soff = nullptr, *doff = nullptr;
+	Segment *rej = nullptr;
+	auto carve = [&]() {
+		ctr = bp->take<Counters>(1);
+		status = bp->take<uint32_t>(64);
+		cnt32 = bp->take<uint32_t>((size_t)nsrc * nb);
+		soff = bp->take<uint64_t>((size_t)nsrc * nb);
+		doff = bp->take<uint64_t>((size_t)nb + 1);
+		rej = bp->take<Segment>(nb);
+	};
+	carve();
+	int rc = slab_reserve(c, sz.off + 4096);
+	if (!rc) rc = pinned_reserve(c, 4096);
+	if (rc) return rc;
+	Bump real(c->slab);
+	bp = &real;
+	carve();
+	HIPCHK(c, hipMemsetAsync(ctr, 0, (char *)(status + 64) - (char *)ctr, c->stream));
+	MergeBase mb = {};
+	for (uint32_t x = 0; x < nsrc; ++x) mb.b[x] = src_base[x];
+	hipLaunchKernelGGL(merge_plan_kernel, dim3(nsrc + 1), dim3(1024), 0, c->stream, d_counts, mb, nsrc, nb, n_expected, cnt32, soff, doff, status);
+	// buckets that fit the registers of a workgroup (shards of <= 2^27 keys at 8 ranks) take merge_place16_kernel, larger
+	// ones (2^30 keys per rank: nsrc x 2^14 keys per bucket) merge_count_kernel
+	const bool in_regs = c->merge_leaf == 1 || (c->merge_leaf == 0 && n_expected / nb <= 12000 && open_bits >= (int)kC16MinBits);
+	if (in_regs) {
+		const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)c->sm_count * 2);
+		const uint32_t G = nsrc <= 2 ? 2 : nsrc <= 4 ? 4 : 8;
+#define MSD_MERGE_LAUNCH(GG)                                                                                                              \
+	hipLaunchKernelGGL((merge_place16_kernel<GG>), dim3(grid), dim3(kC16Th), kC16Lds, c->stream, src, src_cap, dst, (const uint32_t *)cnt32, \
+			   (const uint64_t *)soff, (const uint64_t *)doff, nsrc, nb, (uint32_t)open_bits, first_prefix, rej, ctr, (const uint32_t *)status)
+		if (G == 2) MSD_MERGE_LAUNCH(2); else if (G == 4) MSD_MERGE_LAUNCH(4); else MSD_MERGE_LAUNCH(8);
+#undef MSD_MERGE_LAUNCH
+	} else {
+		const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)c->sm_count);
+		hipLaunchKernelGGL((merge_count_kernel<false>), dim3(grid), dim3(kMcTh), kMcLds, c->stream, src, dst, (const uint32_t *)cnt32,
+				   (const uint64_t *)soff, (const uint64_t *)doff, nsrc, nb, (uint32_t)open_bits, first_prefix, (const Segment *)nullptr,
+				   (const uint32_t *)nullptr, rej, &ctr->nslow16, &ctr->count_ticket3, (const uint32_t *)status);
+	}
+	HIPCHK(c, hipGetLastError());
+	phase_mark(c, "merge leaf");
+	// what the leaf did not take (rare: long or crowded buckets) lies unsorted at its place in dst: the general leaves finish it
+	HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipMemcpyAsync((char *)c->pinned + 1024, status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	Counters hc;
+	memcpy(&hc, c->pinned, sizeof hc);
+	if (*(const uint32_t *)((char *)c->pinned + 1024)) return fail(c, MSD_EINVAL, "merge_buckets: the counts do not add up to the expected %llu keys (or a count exceeds 32 bits)", (unsigned long long)n_expected);
+	const uint32_t nrej = hc.nslow16;
+	phase_end(c);
+	if (nrej) {
+		rc = pinned_reserve(c, (size_t)nrej * sizeof(Segment));
+		if (rc) return rc;
+		HIPCHK(c, hipMemcpyAsync(c->pinned, rej, (size_t)nrej * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(c, hipStreamSynchronize(c->stream));
+		std::vector<Segment> segs((Segment *)c->pinned, (Segment *)c->pinned + nrej);
+		rc = sort_impl<uint32_t, NoVal>(c, dst, nullptr, n_expected, 32, false, 0, 0, nullptr, nullptr, 0, nullptr, 0, &segs);
+		if (rc) return rc;
+	}
+	set_stat(c, "merge_rejected", nrej);
+	return MSD_OK;
+}
+
+extern "C" {
+
+int msd_bucket_bounds_u32(msd_ctx *c, const uint32_t *k, uint64_t n, unsigned shift, uint64_t first, uint32_t nbuckets, uint64_t *bounds)
+{
+	return bounds_impl<uint32_t>(c, k, n, shift, first, nbuckets, bounds);
+}
+int msd_bucket_bounds_u64(msd_ctx *c, const uint64_t *k, uint64_t n, unsigned shift, uint64_t first, uint32_t nbuckets, uint64_t *bounds)
+{
+	return bounds_impl<uint64_t>(c, k, n, shift, first, nbuckets, bounds);
+}
+int msd_merge_buckets_u32(msd_ctx *c, const uint32_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
+			  uint32_t nbuckets, int open_bits, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected)
+{
+	return merge_impl(c, d_src, src_cap, d_counts, src_base, nsrc, nbuckets, open_bits, first_prefix, d_dst, dst_cap, n_expected);
 }
 
 // ---- segmented sort and run gather: what a rank of the multi-GPU sort does with the keys it received
@@ -1582,6 +1742,9 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "count16")) {
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
 		c->count16 = (int)value;
+	} else if (!strcmp(name, "merge_leaf")) {
+		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "merge_leaf must be 0, 1 or 2");
+		c->merge_leaf = (int)value;
 	} else if (!strcmp(name, "direct_kernel")) {
 		(void)value; // (round 1's kernel is gone; the option is accepted for old callers)
 	} else if (!strcmp(name, "direct_min_parent")) {

@@ -16,6 +16,14 @@ ranges per node (numa_dest, src/msb_64.c:1596-1607), blocks balanced across node
      log2(G) bits, which are passed on as ``end_bit`` (the reference passes bits=58 after
      its 6-bit split, src/msb_64.c:2242).
 
+Large evenly spread shards (>= 2^27 keys per rank, with a second buffer) take the FINE scheme instead: the shard is
+ordered by its top 16 bits BEFORE the exchange (``engine.sort_top`` -- two direct-placement rounds, which run at full
+speed on a rank's own uniform keys, whereas what ARRIVES after an exchange is run-structured), the 65536 bucket counts
+are all-gathered, the one all-to-all moves every rank's range of buckets, and ``engine.merge_buckets`` finishes every
+bucket -- ``world`` extents, one per source -- with one counting pass that reads the extents where they arrived and
+writes the sorted bucket to its place in the second buffer: no gather pass, no run-structured round, 7.5-8.5 ms of
+local work per 2^30-key step at 8, 4 and 2 ranks instead of 10.9-11.5 (tools/multigpu_local_work.py).
+
 u64 keys and (u64 key, u64 rid) tuples -- what the reference's ``sort()`` takes, one pair of arrays per memory node --
 shard the same way (``sort_sharded_u64``, ``sort_sharded_pairs_u64``).
 ``engine`` is an :class:`inplacemsdradixsort_amd.MsdContext`; the CPU gloo tests pass a
@@ -118,6 +126,65 @@ def exchange_bucket_counts(dist, counts, capacity: int, world: int, group=None):
     return to_rank[me].tolist(), to_rank[:, me].tolist(), mat[:, me * per:(me + 1) * per].tolist()
 
 
+FINE_BITS = 16          # the fine scheme orders a shard by its top 16 bits before the exchange ...
+FINE_MIN_KEYS = 1 << 27  # ... when a rank holds at least this many keys (buckets of >= 2^11 keys per source)
+
+
+def use_fine(n_keys: int, world: int, have_work: bool, scheme=None) -> bool:
+    """Which scheme ``sort_sharded_u32`` / ``ShardedSorter`` take: ``scheme`` "fine" / "coarse" forces one (tests,
+    experiments); by default the fine scheme runs when there is a second buffer, 2..8 ranks and a large shard.  Every
+    rank must come to the same answer: shards of one call should be equally long (they are in bench.py)."""
+    if scheme == "coarse" or world < 2 or not have_work:
+        return False
+    if scheme == "fine":
+        return True
+    return world <= 8 and n_keys >= FINE_MIN_KEYS
+
+
+def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
+    """The fine scheme's count exchange: ``counts`` = this rank's 2^16 bucket sizes (int64, on the device).  One
+    all-gather of 2^16 + 1 int64 per rank; the world x world send matrix and the capacities come to the host in ONE
+    small copy, the per-bucket counts stay on the device.  Returns (send_list, recv_list, mine): ``mine`` = int64
+    [world, 2^16 / world] on the device -- row s: the lengths of source s's extents of this rank's buckets, in arrival
+    order.  Raises :class:`ReceiveOverflow` on every rank if any rank's total exceeds its capacity."""
+    import torch
+    nb = 1 << FINE_BITS
+    row = torch.cat([counts.to(torch.int64), torch.tensor([capacity], dtype=torch.int64, device=counts.device)])
+    rows = [torch.empty_like(row) for _ in range(world)]
+    dist.all_gather(rows, row, group=group)
+    allc = torch.stack(rows)                                      # [sender, bucket | capacity], on the device
+    nbl = nb // world
+    to_rank = allc[:, :nb].view(world, world, nbl).sum(dim=2)     # [sender, destination]
+    small = torch.cat([to_rank.reshape(-1), allc[:, nb]]).cpu()   # one D2H: world^2 + world numbers
+    to_rank_h, caps = small[:world * world].view(world, world), small[world * world:]
+    totals = to_rank_h.sum(dim=0)
+    over = [(r, int(totals[r]), int(caps[r])) for r in range(world) if int(totals[r]) > int(caps[r])]
+    if over:
+        raise ReceiveOverflow("receive buffer too small on rank(s) " +
+                              ", ".join(f"{r}: {t} keys for capacity {c}" for r, t, c in over) +
+                              " (raise the slack -- the reference's fudge -- or use sort_sharded_u32_sampled)")
+    me = _rank(dist, group)
+    mine = allc[:, me * nbl:(me + 1) * nbl].contiguous()
+    return to_rank_h[me].tolist(), to_rank_h[:, me].tolist(), mine
+
+
+def _fine_counts(engine, keys):
+    """Orders the shard by its top 16 bits and returns its 2^16 bucket sizes (int64, on the device)."""
+    engine.sort_top(keys, 32 - FINE_BITS)
+    b = engine.bucket_bounds(keys, 32 - FINE_BITS, 1 << FINE_BITS)
+    return b[1:] - b[:-1]
+
+
+def _fine_finish(engine, arrived, out, mine, got_l, rank: int, world: int):
+    """The counting leaf over what arrived: source s's extents lie back to back from sum(got_l[:s]) on."""
+    base, at = [], 0
+    for g in got_l:
+        base.append(at)
+        at += int(g)
+    engine.merge_buckets(arrived, mine, base, 32 - FINE_BITS, rank * ((1 << FINE_BITS) // world), out, at)
+    return out[:at]
+
+
 def bucket_major(mine):
     """The runs a rank received (``mine[s][j]``: source-major, as the all-to-all delivers them) and where each belongs
     when every bucket is to be contiguous: (src_off, dst_off, lens) for ``engine.gather_runs`` and the bucket
@@ -142,9 +209,13 @@ def bucket_major(mine):
     return src_off, dst_off, lens, seg_off
 
 
-def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None):
+def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None, scheme=None):
     """Sorts the union of all ranks' ``keys`` (int32 tensors holding u32 bit patterns).
     Returns this rank's sorted range; rank r's range precedes rank r+1's.
+
+    ``scheme``: None = choose (:func:`use_fine`), "fine" / "coarse" = force.  The fine scheme (module docstring)
+    needs ``work``; its result is a view of ``work``, and ``recv`` must hold what arrives plus up to 3 elements
+    (the leaf reads whole 16-byte vectors).
 
     With a second buffer ``work`` (as large as ``recv``) the local sort does not repeat the top-digit pass: the runs
     that arrived (per source, that source's buckets of this rank's range) are gathered bucket-major into ``work`` in
@@ -154,6 +225,11 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
     if world == 1:
         engine.sort_u32(keys)
         return keys
+    if use_fine(keys.numel(), world, work is not None, scheme):
+        send_l, got_l, mine = exchange_fine_counts(dist, _fine_counts(engine, keys), min(recv.numel(), work.numel()), world, group)
+        m = int(sum(got_l))
+        dist.all_to_all_single(recv[:m], keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+        return _fine_finish(engine, recv, work, mine, got_l, _rank(dist, group), world)
     counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
     if work is None or world > 4:                                # (8 ranks and more: see ShardedSorter)
         send = counts.view(world, 256 // world).sum(dim=1)       # keys per destination rank
@@ -229,8 +305,10 @@ class ShardedSorter:
     untouched until the matching ``collect`` returns.
     """
 
-    def __init__(self, engine, dist, world: int, recv_bufs, group=None, work_bufs=None):
+    def __init__(self, engine, dist, world: int, recv_bufs, group=None, work_bufs=None, scheme=None):
         self.engine, self.dist, self.world, self.group = engine, dist, world, group
+        self.scheme = scheme              # None: by shard size (use_fine); "fine" / "coarse": forced
+        self.fine_work = list(work_bufs) if work_bufs else []   # the fine scheme uses the work buffers at any rank count
         self.lg = _log2(world)
         self.recv = list(recv_bufs)
         if world > 1 and len(self.recv) < 2:
@@ -245,14 +323,23 @@ class ShardedSorter:
         self._wslot = 0
         self._slot = 0
         self._pending = []
+        self._async = None
 
     def _all_to_all(self, out, keys, got_l, send_l):
-        try:      # torch.distributed: returns a Work whose wait() orders the current stream after it
+        # torch.distributed returns a Work whose wait() orders the current stream after the exchange; stand-ins without
+        # ``async_op`` (HostStagedDist, tests) exchange synchronously.  Decided once from the signature -- a TypeError
+        # raised by the real backend (bad split list, dtype) is an error, not a reason to run the collective again.
+        if self._async is None:
+            import inspect
+            try:
+                self._async = "async_op" in inspect.signature(self.dist.all_to_all_single).parameters
+            except (TypeError, ValueError):
+                self._async = False
+        if self._async:
             return self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l,
                                                group=self.group, async_op=True)
-        except TypeError:  # stand-ins without async_op (tests)
-            self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=self.group)
-            return None
+        self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=self.group)
+        return None
 
     def submit(self, keys) -> None:
         if self.world == 1:
@@ -260,8 +347,15 @@ class ShardedSorter:
             return
         if len(self._pending) >= len(self.recv):
             raise RuntimeError("collect() before submitting more shards than there are receive buffers")
-        counts = self.engine.partition(keys, 24, 8)
         recv = self.recv[self._slot]
+        if use_fine(keys.numel(), self.world, bool(self.fine_work), self.scheme):
+            cap = min(recv.numel(), min(w.numel() for w in self.fine_work))
+            send_l, got_l, mine = exchange_fine_counts(self.dist, _fine_counts(self.engine, keys), cap, self.world, self.group)  # raises on all ranks
+            self._slot = (self._slot + 1) % len(self.recv)
+            out = recv[:int(sum(got_l))]
+            self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), ("fine", recv, mine, got_l)))
+            return
+        counts = self.engine.partition(keys, 24, 8)
         mine = None
         if self.work:
             cap = min(recv.numel(), min(w.numel() for w in self.work))
@@ -277,6 +371,11 @@ class ShardedSorter:
         out, handle, mine = self._pending.pop(0)
         if handle is not None:
             handle.wait()
+        if isinstance(mine, tuple):   # fine scheme: the counting leaf reads the extents in the receive buffer, writes a work buffer
+            _, recv, counts, got_l = mine
+            final = self.fine_work[self._wslot]
+            self._wslot = (self._wslot + 1) % len(self.fine_work)
+            return _fine_finish(self.engine, recv, final, counts, got_l, _rank(self.dist, self.group), self.world)
         if mine is None:
             if self.world > 1:
                 self.engine.sort_u32(out, end_bit=32 - self.lg)

@@ -41,6 +41,36 @@ class NumpyEngine:
                 assert int(hb.min()) == int(hb.max())           # a segment's keys agree above end_bit
                 a[lo:hi].sort()
 
+    # fine scheme: order by the top bits, bucket boundaries, the counting leaf over the arrived extents
+    def sort_top(self, keys, begin_bit, end_bit=None, rids=None):
+        a = keys.numpy().view(np.uint32 if keys.element_size() == 4 else np.uint64)
+        order = np.argsort(a >> a.dtype.type(begin_bit), kind="stable")   # (keys that agree above begin_bit stay in input order)
+        a[:] = a[order]
+        if rids is not None:
+            r = rids.numpy()
+            r[:] = r[order]
+
+    def bucket_bounds(self, keys, shift, nbuckets, first=0):
+        a = keys.numpy().view(np.uint32 if keys.element_size() == 4 else np.uint64).astype(np.uint64) >> np.uint64(shift)
+        assert (np.diff(a.astype(np.int64)) >= 0).all()
+        return torch.from_numpy(np.searchsorted(a, np.arange(first, first + nbuckets + 1, dtype=np.uint64), side="left").astype(np.int64))
+
+    def merge_buckets(self, src, counts, src_base, open_bits, first_prefix, dst, n_expected):
+        s_, d, c = src.numpy().view(np.uint32), dst.numpy().view(np.uint32), counts.numpy()
+        nsrc, nb = c.shape
+        assert int(c.sum()) == n_expected <= d.size
+        pos = [int(b) for b in src_base]
+        at = 0
+        for j in range(nb):
+            parts = []
+            for x in range(nsrc):
+                parts.append(s_[pos[x]:pos[x] + int(c[x, j])])
+                pos[x] += int(c[x, j])
+            b = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+            assert ((b >> np.uint32(open_bits)) == first_prefix + j).all()   # every extent holds keys of its bucket only
+            d[at:at + b.size] = np.sort(b)
+            at += b.size
+
     def sort_u64(self, keys, end_bit=64):
         a = keys.numpy().view(np.uint64)
         if a.size and end_bit < 64:
@@ -101,6 +131,8 @@ def _worker(rank, world, port, n, kind, q, sampled=False):
     recv = torch.empty(n * world, dtype=torch.int32)
     if sampled == "work":   # gather bucket-major into a second buffer, segmented local sort
         out = sort_sharded_u32(NumpyEngine(), keys, recv, dist, world, work=torch.empty(n * world, dtype=torch.int32))
+    elif sampled == "fine":  # top 16 bits before the exchange, counting leaf over the arrived extents after it
+        out = sort_sharded_u32(NumpyEngine(), keys, recv, dist, world, work=torch.empty(n * world, dtype=torch.int32), scheme="fine")
     else:
         fn = sort_sharded_u32_sampled if sampled else sort_sharded_u32
         out = fn(NumpyEngine(), keys, recv, dist, world)
@@ -110,13 +142,14 @@ def _worker(rank, world, port, n, kind, q, sampled=False):
 
 
 @pytest.mark.parametrize("world,kind,work", [(2, "uniform", False), (4, "uniform", False), (2, "zipf", False), (8, "uniform", False),
-                                             (2, "zipf", True), (4, "uniform", True), (8, "uniform", True)])
+                                             (2, "zipf", True), (4, "uniform", True), (8, "uniform", True),
+                                             (2, "uniform", "fine"), (4, "zipf", "fine"), (8, "uniform", "fine")])
 def test_sharded_sort_over_gloo(world, kind, work):
     n = 20000 if world < 8 else 6000   # (8 ranks: each owns 32 top-digit buckets, BASELINE config C4's geometry)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q, "work" if work else False)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q, work if isinstance(work, str) else ("work" if work else False))) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
@@ -134,7 +167,7 @@ def test_sharded_sort_over_gloo(world, kind, work):
             assert ((res[r] >> np.uint32(32 - lg)) == r).all()
 
 
-def _pipeline_worker(rank, world, port, n, shards, q):
+def _pipeline_worker(rank, world, port, n, shards, q, scheme=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -142,8 +175,8 @@ def _pipeline_worker(rank, world, port, n, shards, q):
     from oracle import oracle as O
     bufs = [torch.from_numpy(O.gen_uniform_u32(n, seed=100 + s, first=rank * n).view(np.int32).copy()) for s in range(shards)]
     recv = [torch.empty(n * world, dtype=torch.int32) for _ in range(2)]
-    work = [torch.empty(n * world, dtype=torch.int32) for _ in range(2)] if world != 2 else None   # (2 ranks: sorted where they arrive)
-    sorter = ShardedSorter(NumpyEngine(), dist, world, recv, work_bufs=work)
+    work = [torch.empty(n * world, dtype=torch.int32) for _ in range(2)] if (world != 2 or scheme) else None   # (2 ranks: sorted where they arrive)
+    sorter = ShardedSorter(NumpyEngine(), dist, world, recv, work_bufs=work, scheme=scheme)
     outs = []
     for s in range(shards):        # the order bench.py uses: submit shard s, then finish shard s-1
         sorter.submit(bufs[s])
@@ -156,14 +189,14 @@ def _pipeline_worker(rank, world, port, n, shards, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_pipelined_sharded_sorter_over_gloo(world):
+@pytest.mark.parametrize("world,scheme", [(2, None), (4, None), (8, None), (2, "fine"), (8, "fine")])
+def test_pipelined_sharded_sorter_over_gloo(world, scheme):
     """ShardedSorter (exchange of shard s in flight while shard s-1 is sorted) gives every shard's sorted ranges."""
     n, shards = (12000, 4) if world < 8 else (4000, 3)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, n, shards, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, n, shards, q, scheme)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
@@ -211,7 +244,8 @@ def _overflow_worker(rank, world, port, n, q):
     recv = torch.empty(n + n // 8, dtype=torch.int32)                                  # bench.py's 12.5 % slack
     got = []
     for fn in (lambda: sort_sharded_u32(NumpyEngine(), keys.clone(), recv, dist, world),
-               lambda: ShardedSorter(NumpyEngine(), dist, world, [recv, recv.clone()]).submit(keys.clone())):
+               lambda: ShardedSorter(NumpyEngine(), dist, world, [recv, recv.clone()]).submit(keys.clone()),
+               lambda: sort_sharded_u32(NumpyEngine(), keys.clone(), recv, dist, world, work=recv.clone(), scheme="fine")):
         try:
             fn()
             got.append("no error")
@@ -237,7 +271,7 @@ def test_receive_overflow_is_raised_on_every_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     for r in range(world):
-        assert len(res[r]) == 2 and all("receive buffer too small on rank(s) 0:" in m for m in res[r]), res[r]
+        assert len(res[r]) == 3 and all("receive buffer too small on rank(s) 0:" in m for m in res[r]), res[r]
 
 
 def test_splitters_follow_the_reference_duplicate_rule():

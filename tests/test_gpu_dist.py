@@ -56,20 +56,22 @@ def _worker(rank, world, port, n, kind, q, sampled=False):
     (ctx.gen_uniform_u32 if kind == "uniform" else ctx.gen_zipf_u32)(keys, first=rank * n)
     v0, s0, x0 = ctx.check(keys)
     recv = torch.empty(n * world, dtype=torch.int32, device="cuda:0")
-    if sampled == "work":   # runs gathered bucket-major into a second buffer, segmented local sort (bench.py's N > 1 path)
-        out = sort_sharded_u32(ctx, keys, recv, GlooViaCpu, world, work=torch.empty(n * world, dtype=torch.int32, device="cuda:0"))
+    if sampled == "work":   # runs gathered bucket-major into a second buffer, segmented local sort (round 2's N > 1 path)
+        out = sort_sharded_u32(ctx, keys, recv, GlooViaCpu, world, work=torch.empty(n * world, dtype=torch.int32, device="cuda:0"), scheme="coarse")
+    elif sampled == "fine":  # top 16 bits before the exchange, counting leaf over the arrived extents (bench.py's N > 1 path)
+        out = sort_sharded_u32(ctx, keys, recv, GlooViaCpu, world, work=torch.empty(n * world, dtype=torch.int32, device="cuda:0"), scheme="fine")
     else:
         out = (sort_sharded_u32_sampled if sampled else sort_sharded_u32)(ctx, keys, recv, GlooViaCpu, world)
     v, s, x = ctx.check(out)
     lo = int(out[0].item()) & 0xFFFFFFFF if out.numel() else -1
     hi = int(out[-1].item()) & 0xFFFFFFFF if out.numel() else -1
-    q.put((rank, out.numel(), v, s0, x0, s, x, lo, hi))
+    q.put((rank, out.numel(), v, s0, x0, s, x, lo, hi, out.cpu().numpy().view(np.uint32).copy()))
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
 
 
-def _pipeline_worker(rank, world, port, n, shards, q):
+def _pipeline_worker(rank, world, port, n, shards, q, scheme=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -85,14 +87,14 @@ def _pipeline_worker(rank, world, port, n, shards, q):
         sums.append(ctx.check(t)[1:])
     recv = [torch.empty(n * world, dtype=torch.int32, device="cuda:0") for _ in range(2)]
     work = [torch.empty(n * world, dtype=torch.int32, device="cuda:0") for _ in range(2)]
-    sorter = ShardedSorter(ctx, GlooViaCpu, world, recv, work_bufs=work)
+    sorter = ShardedSorter(ctx, GlooViaCpu, world, recv, work_bufs=work, scheme=scheme)
     res = []
 
     def take(out):
         v, s_, x_ = ctx.check(out)
         lo = int(out[0].item()) & 0xFFFFFFFF if out.numel() else -1
         hi = int(out[-1].item()) & 0xFFFFFFFF if out.numel() else -1
-        res.append((out.numel(), v, s_, x_, lo, hi))
+        res.append((out.numel(), v, s_, x_, lo, hi, out.cpu().numpy().view(np.uint32).copy()))
 
     for s in range(shards):
         sorter.submit(bufs[s])
@@ -105,13 +107,15 @@ def _pipeline_worker(rank, world, port, n, shards, q):
     ctx.close()
 
 
-def test_pipelined_sharded_sorter_real_engine():
-    """bench.py's N > 1 loop (ShardedSorter) with the HIP engine: 2 ranks on one device, 3 shards in a row."""
+@pytest.mark.parametrize("scheme", ["coarse", "fine"])
+def test_pipelined_sharded_sorter_real_engine(scheme):
+    """bench.py's N > 1 loop (ShardedSorter) with the HIP engine: 2 ranks on one device, 3 shards in a row; the
+    concatenated outputs equal the sorted union of the regenerated inputs."""
     world, n, shards = 2, 1 << 22, 3
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_pipeline_worker, args=(r, world, port, n, shards, q)) for r in range(world)]
+    procs = [mpc.Process(target=_pipeline_worker, args=(r, world, port, n, shards, q, scheme)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=300) for _ in range(world))
@@ -131,15 +135,19 @@ def test_pipelined_sharded_sorter_real_engine():
             out_xor ^= x[3]
         assert sum(x[2] for x in per_rank) & (2 ** 64 - 1) == in_sum and out_xor == in_xor
         assert per_rank[0][5] < per_rank[1][4]                        # rank 0's range precedes rank 1's
+        from oracle import oracle as O
+        allk = np.concatenate([O.gen_uniform_u32(n, seed=500 + s, first=r * n) for r in range(world)])
+        assert (np.concatenate([x[6] for x in per_rank]) == np.sort(allk)).all()
 
 
 @pytest.mark.parametrize("world,kind,n,work", [(2, "uniform", 1 << 22, False), (4, "uniform", 1 << 20, False), (2, "zipf", 1 << 21, False),
-                                               (2, "uniform", 1 << 22, True), (4, "zipf", 1 << 20, True)])
+                                               (2, "uniform", 1 << 22, True), (4, "zipf", 1 << 20, True),
+                                               (2, "uniform", 1 << 22, "fine"), (4, "uniform", 1 << 21, "fine"), (4, "zipf", 1 << 20, "fine")])
 def test_sharded_sort_real_engine(world, kind, n, work):
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, world, port, n, kind, q, "work" if work else False)) for r in range(world)]
+    procs = [mpc.Process(target=_worker, args=(r, world, port, n, kind, q, work if isinstance(work, str) else ("work" if work else False))) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=300) for _ in range(world))
@@ -162,6 +170,11 @@ def test_sharded_sort_real_engine(world, kind, n, work):
         if r[1]:
             assert (r[7] >> (32 - lg)) == r[0] and (r[8] >> (32 - lg)) == r[0] and r[7] > prev_hi
             prev_hi = r[8]
+    # the exact result: the ranks' outputs, concatenated, are the sorted union of the (regenerated) inputs
+    from oracle import oracle as O
+    gen = O.gen_uniform_u32 if kind == "uniform" else O.gen_zipf_u32
+    allk = np.concatenate([gen(n, first=r * n) for r in range(world)])
+    assert (np.concatenate([r[9] for r in res]) == np.sort(allk)).all()
 
 
 @pytest.mark.parametrize("world,kind,n", [(2, "zipf", 1 << 21), (4, "zipf", 1 << 20)])
@@ -185,6 +198,9 @@ def test_sampled_splitter_sort_real_engine(world, kind, n):
             assert r[7] > prev_hi                                      # ranges (delim[p-1], delim[p]] do not share a value
             prev_hi = r[8]
     assert max(r[1] for r in res) < 1.35 * n      # balanced although 75 % of the keys share the top byte
+    from oracle import oracle as O
+    allk = np.concatenate([O.gen_zipf_u32(n, first=r * n) for r in range(world)])
+    assert (np.concatenate([r[9] for r in res]) == np.sort(allk)).all()
 
 
 def _pairs_worker(rank, world, port, n, q):
@@ -205,7 +221,7 @@ def _pairs_worker(rank, world, port, n, q):
     M = (1 << 64) - 1
     lo = int(out_k[0].item()) & M if out_k.numel() else -1
     hi = int(out_k[-1].item()) & M if out_k.numel() else -1
-    q.put((rank, out_k.numel(), v, s0, x0, s, x, lo, hi))
+    q.put((rank, out_k.numel(), v, s0, x0, s, x, lo, hi, out_k.cpu().numpy().view(np.uint64).copy()))
     dist.barrier()
     dist.destroy_process_group()
     ctx.close()
@@ -237,3 +253,6 @@ def test_sharded_tuple_sort_real_engine(world, n):
     for r in res:
         if r[1]:
             assert (r[7] >> (64 - lg)) == r[0] and (r[8] >> (64 - lg)) == r[0]
+    from oracle import oracle as O
+    allk = np.concatenate([O.gen_uniform_u64(n, first=r * n) for r in range(world)])
+    assert (np.concatenate([r[9] for r in res]) == np.sort(allk)).all()   # the exact key sequence (rid == key was checked on the device)

@@ -1,0 +1,223 @@
+"""Fine-grained sharding building blocks (include/msd_radix_hip.h): msd_sort_*_top (a sort that stops at a bit),
+msd_bucket_bounds_* and msd_merge_buckets_u32 (the counting leaf that reads a bucket's extents where the all-to-all put
+them) -- against the oracle / numpy, through the C ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int32 if a.dtype == np.uint32 else np.int64)).cuda()
+
+
+def host(t, dt):
+    return t.cpu().numpy().view(dt)
+
+
+@pytest.mark.parametrize("begin_bit", [0, 8, 16, 20, 32])
+@pytest.mark.parametrize("n", [1, 1000, 30_000, (1 << 20) + 13, 1 << 23])
+def test_sort_u32_top(ctx, n, begin_bit):
+    from oracle import oracle as O
+    k = O.gen_uniform_u32(n, seed=n + begin_bit)
+    t = dev(k)
+    ctx.sort_top(t, begin_bit)
+    out = host(t, np.uint32)
+    top = out.astype(np.uint64) >> np.uint64(begin_bit)
+    assert (np.diff(top.astype(np.int64)) >= 0).all()              # ordered by key >> begin_bit
+    assert (np.sort(out) == O.sort_u32(k)).all()                   # the same keys
+
+
+def test_sort_u32_top_skewed_and_constant(ctx):
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for k in (O.gen_zipf_u32(1 << 21, seed=3), np.full(1 << 20, 0xDEADBEEF, dtype=np.uint32),
+              (rng.integers(0, 1 << 12, 1 << 21, dtype=np.uint32)),   # every varying bit below begin_bit: nothing to do
+              (rng.integers(0, 1 << 12, 1 << 21, dtype=np.uint32) << np.uint32(18))):
+        t = dev(k)
+        ctx.sort_top(t, 16)
+        out = host(t, np.uint32)
+        assert (np.diff((out >> np.uint32(16)).astype(np.int64)) >= 0).all()
+        assert (np.sort(out) == np.sort(k)).all()
+
+
+def test_sort_top_u64_and_pairs(ctx):
+    from oracle import oracle as O
+    n = (1 << 21) + 5
+    k = O.gen_uniform_u64(n, seed=77)
+    t = dev(k)
+    ctx.sort_top(t, 40)
+    out = host(t, np.uint64)
+    assert (np.diff((out >> np.uint64(40)).astype(np.int64)) >= 0).all()
+    assert (np.sort(out) == O.sort_u64(k)).all()
+    tk, tr = dev(k), dev(k)
+    ctx.sort_top(tk, 48, rids=tr)
+    ok, orr = host(tk, np.uint64), host(tr, np.uint64)
+    assert (ok == orr).all() and (np.diff((ok >> np.uint64(48)).astype(np.int64)) >= 0).all()
+    assert (np.sort(ok) == O.sort_u64(k)).all()
+
+
+@pytest.mark.parametrize("shift,nb,first", [(16, 1 << 16, 0), (24, 256, 0), (16, 8192, 8192 * 3), (20, 100, 4000)])
+def test_bucket_bounds(ctx, shift, nb, first):
+    rng = np.random.default_rng(shift + nb)
+    k = np.sort(rng.integers(0, 1 << 32, 500_000, dtype=np.uint64).astype(np.uint32))
+    b = ctx.bucket_bounds(dev(k), shift, nb, first).cpu().numpy()
+    want = np.searchsorted(k.astype(np.uint64) >> np.uint64(shift), np.arange(first, first + nb + 1, dtype=np.uint64), side="left")
+    assert (b == want).all()
+    e = ctx.bucket_bounds(dev(np.zeros(0, dtype=np.uint32)), shift, nb, first).cpu().numpy()   # empty input
+    assert (e == 0).all()
+
+
+def _arrivals(rng, nsrc, nb, first, open_bits, per_bucket, gaps, heavy=None):
+    """What a rank holds after a fine-grained exchange: per source, that source's buckets first .. first + nb - 1 in
+    order (unsorted inside a bucket), sources back to back with ``gaps[x]`` elements of junk in front of source x."""
+    rows, counts, base, at = [], np.zeros((nsrc, nb), dtype=np.int64), [], 0
+    parts = []
+    for x in range(nsrc):
+        c = rng.poisson(per_bucket / nsrc, nb).astype(np.int64)
+        if heavy is not None:
+            c[heavy[0]] = heavy[1] // nsrc
+        counts[x] = c
+        pre = np.repeat(np.arange(first, first + nb, dtype=np.uint64), c)
+        low = rng.integers(0, 1 << open_bits, int(c.sum()), dtype=np.uint64)
+        keys = ((pre << np.uint64(open_bits)) | low).astype(np.uint32)
+        parts.append(np.full(gaps[x], 0xFFFFFFFF, dtype=np.uint32))
+        at += gaps[x]
+        base.append(at)
+        parts.append(keys)
+        rows.append(keys)
+        at += keys.size
+    parts.append(np.full(8, 0xFFFFFFFF, dtype=np.uint32))
+    return np.concatenate(parts), counts, base, np.concatenate(rows)
+
+
+@pytest.mark.parametrize("nsrc,nb,per_bucket,open_bits", [
+    (2, 512, 16384, 16), (4, 512, 16384, 16), (8, 512, 16384, 16),     # the multi-GPU shape: 2^14-key buckets
+    (3, 300, 9000, 16), (8, 2000, 700, 12), (5, 64, 17000, 16), (8, 128, 17300, 16),   # odd source counts, narrow values, nearly full buckets
+    (1, 100, 5000, 16), (8, 4096, 3, 9), (2, 100, 500, 6),
+])
+def test_merge_buckets_equals_sort(ctx, nsrc, nb, per_bucket, open_bits):
+    import torch
+    rng = np.random.default_rng(nsrc * 1000 + nb)
+    first = 5 * nb if (5 * nb + nb) <= (1 << (32 - open_bits)) else 0
+    gaps = [int(g) for g in rng.integers(0, 7, nsrc)]
+    src, counts, base, allk = _arrivals(rng, nsrc, nb, first, open_bits, per_bucket, gaps)
+    n = int(counts.sum())
+    dst = torch.full((n + 5,), -1, dtype=torch.int32, device="cuda")
+    ctx.merge_buckets(dev(src), torch.from_numpy(counts).cuda(), base, open_bits, first, dst, n)
+    out = host(dst, np.uint32)
+    assert (out[:n] == np.sort(allk)).all()
+    assert (out[n:] == 0xFFFFFFFF).all()                              # nothing written behind the last bucket
+
+
+@pytest.mark.parametrize("nsrc,nb,per_bucket,open_bits", [
+    (8, 24, 131072, 16), (4, 40, 65536, 16), (2, 64, 32768, 16),       # 2^30 keys per rank: nsrc x 2^14 keys per bucket
+    (3, 50, 40000, 16), (8, 300, 3000, 12), (1, 10, 200000, 16), (8, 2000, 5, 7), (5, 6, 700000, 16), (2, 3, 900000, 16),
+])
+def test_merge_buckets_counting_kernel(ctx, nsrc, nb, per_bucket, open_bits):
+    """merge_count_kernel forced (it is chosen by bucket size otherwise): 16-bit LDS counters, value-parallel tiles."""
+    import torch
+    rng = np.random.default_rng(nsrc * 77 + nb)
+    first = 3 * nb
+    gaps = [int(g) for g in rng.integers(0, 7, nsrc)]
+    src, counts, base, allk = _arrivals(rng, nsrc, nb, first, open_bits, per_bucket, gaps)
+    counts[:, nb // 2] = 0                                            # an empty bucket in the middle
+    src, allk = _rebuild(src, counts, base, gaps, first, open_bits, rng)
+    n = int(counts.sum())
+    dst = torch.full((n + 5,), -1, dtype=torch.int32, device="cuda")
+    ctx.set_option("merge_leaf", 2)
+    try:
+        ctx.merge_buckets(dev(src), torch.from_numpy(counts).cuda(), base, open_bits, first, dst, n)
+    finally:
+        ctx.set_option("merge_leaf", 0)
+    out = host(dst, np.uint32)
+    assert (out[:n] == np.sort(allk)).all()
+    assert (out[n:] == 0xFFFFFFFF).all()
+
+
+def _rebuild(src, counts, base, gaps, first, open_bits, rng):
+    """Arrival buffer for edited ``counts`` (same layout rules as _arrivals)."""
+    nsrc, nb = counts.shape
+    parts, rows, at = [], [], 0
+    for x in range(nsrc):
+        c = counts[x]
+        pre = np.repeat(np.arange(first, first + nb, dtype=np.uint64), c)
+        low = rng.integers(0, 1 << open_bits, int(c.sum()), dtype=np.uint64)
+        keys = ((pre << np.uint64(open_bits)) | low).astype(np.uint32)
+        parts.append(np.full(gaps[x], 0xFFFFFFFF, dtype=np.uint32))
+        at += gaps[x]
+        base[x] = at
+        parts.append(keys)
+        rows.append(keys)
+        at += keys.size
+    parts.append(np.full(8, 0xFFFFFFFF, dtype=np.uint32))
+    return np.concatenate(parts), np.concatenate(rows)
+
+
+def test_merge_counting_kernel_duplicates(ctx):
+    """Long runs of equal keys (filled by whole waves), a key with more copies than a 16-bit counter holds and a
+    256-value group with more keys than a 16-bit offset addresses (both: not taken, finished by the general leaves)."""
+    import torch
+    rng = np.random.default_rng(4)
+    nsrc, nb = 4, 6
+    counts = np.full((nsrc, nb), 30000, dtype=np.int64)
+    base, gaps = [0] * nsrc, [1, 0, 3, 2]
+    src, allk = _rebuild(None, counts, base, gaps, 0, 16, rng)
+    def bucket_slice(x, j):
+        a = base[x] + int(counts[x, :j].sum())
+        return slice(a, a + int(counts[x, j]))
+    for x in range(nsrc):
+        src[bucket_slice(x, 1)] &= np.uint32(0xFFFF3F00)              # bucket 1: 64 distinct keys in 64 groups, ~1900 copies each
+        src[bucket_slice(x, 2)] = np.uint32((2 << 16) | 77)           # bucket 2: one key, 120000 copies
+        src[bucket_slice(x, 4)] &= np.uint32(0xFFFF00FF)              # bucket 4: all keys in one 256-value group
+    allk = np.concatenate([src[base[x]:base[x] + int(counts[x].sum())] for x in range(nsrc)])
+    n = int(counts.sum())
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.set_option("merge_leaf", 2)
+    try:
+        ctx.merge_buckets(dev(src), torch.from_numpy(counts).cuda(), base, 16, 0, dst, n)
+    finally:
+        ctx.set_option("merge_leaf", 0)
+    assert (host(dst, np.uint32) == np.sort(allk)).all()
+    assert ctx.stats().get("merge_rejected", 0) == 2
+
+
+def test_merge_buckets_rejections_are_finished(ctx):
+    """Buckets the leaf does not take -- longer than it holds, more than 255 copies of one key -- go through the
+    general leaves and still come out sorted."""
+    import torch
+    rng = np.random.default_rng(9)
+    src, counts, base, allk = _arrivals(rng, 4, 256, 0, 16, 8000, [0, 1, 2, 3], heavy=(17, 60000))
+    # ... and a bucket that is all one key (byte counters overflow)
+    x0, j = 0, 40
+    a = base[x0] + int(counts[x0, :j].sum())
+    src[a:a + counts[x0, j]] = (np.uint32(j) << np.uint32(16)) | np.uint32(0x1234)
+    allk = np.concatenate([src[base[x]:base[x] + int(counts[x].sum())] for x in range(4)])
+    n = int(counts.sum())
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.merge_buckets(dev(src), torch.from_numpy(counts).cuda(), base, 16, 0, dst, n)
+    assert (host(dst, np.uint32) == np.sort(allk)).all()
+    assert ctx.stats().get("merge_rejected", 0) >= 1
+
+
+def test_merge_buckets_argument_errors(ctx):
+    import torch
+    from inplacemsdradixsort_amd.api import MsdError
+    src = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    dst = torch.zeros(1024, dtype=torch.int32, device="cuda")
+    counts = torch.full((2, 4), 100, dtype=torch.int64, device="cuda")
+    with pytest.raises(MsdError):
+        ctx.merge_buckets(src, counts, [0, 400], 16, 0, dst, 801)     # the counts add up to 800
+    with pytest.raises(MsdError):
+        ctx.merge_buckets(src, counts, [0, 400], 16, 0, src, 800)     # overlap
+    with pytest.raises(MsdError):
+        ctx.merge_buckets(src, counts, [0, 400], 17, 0, dst, 800)     # open bits
+    with pytest.raises(MsdError):
+        ctx.merge_buckets(src, counts, [0, 400], 16, 0, dst[:100], 800)   # output too small

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
-"""What one rank of the N-GPU sort does per step, timed on ONE GPU (RCCL cannot run here): the top-digit pass before
-the exchange, then -- on keys laid out as they arrive, per source rank that source's buckets of the rank's range --
-the run gather and the segmented sort, next to the sort on 32 - log2(N) bits they replace.
+"""What one rank of the N-GPU sort does per step, timed on ONE GPU (RCCL cannot run here).
+
+Two schemes (inplacemsdradixsort_amd/dist.py):
+  fine   -- before the exchange the rank orders its (uniform, unmasked) shard by the top 16 bits and finds the bucket
+            boundaries; after it, the counting leaf reads every bucket's G extents where they arrived (msd_merge_buckets_u32).
+  coarse -- one top-digit pass before the exchange; after it the arrived runs are gathered bucket-major and sorted as
+            segments on 24 bits (round 2's scheme), or sorted where they are on 32 - log2(N) bits.
+"before the exchange" is timed on the rank's own shard (uniform over all 32 bits -- round 2's version of this tool
+masked the keys first and so timed a partition whose keys sat in 256 / N buckets); "after the exchange" on keys laid out
+as the all-to-all delivers them: N sources, each with its buckets of this rank's range in order.
 
     python tools/multigpu_local_work.py [ranks=8] [logn=30]     # one JSON line
 """
 import json
 import os
 import sys
-
-import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
@@ -22,12 +27,15 @@ from inplacemsdradixsort_amd.dist import bucket_major  # noqa: E402
 
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 logn = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+lg = G.bit_length() - 1
 n, per = 1 << logn, 256 // G
+nbl = 65536 // G
 ctx = MsdContext(0)
 ctx.use_torch_stream()
 keys = torch.empty(n, dtype=torch.int32, device="cuda")
-arrived = torch.empty(n, dtype=torch.int32, device="cuda")
+arrived = torch.empty(n + 64, dtype=torch.int32, device="cuda")
 work = torch.empty(n, dtype=torch.int32, device="cuda")
+ctx.reserve(n + n // 8, 4, 0)
 
 
 def timed(f):
@@ -40,25 +48,89 @@ def timed(f):
     return e0.elapsed_time(e1)
 
 
-res = {"ranks": G, "keys_per_rank": n, "ms": {}}
+best = {}
+
+
+def note(name, ms):
+    best[name] = min(best.get(name, 1e9), ms)
+
+
+stamps = None
+from inplacemsdradixsort_amd import _lib  # noqa: E402
+L = _lib.load(build_if_missing=False)
+
+
+def read_stamps():
+    """a -DMSD_STAMPS=8 build: cycles per section of merge_count_kernel for one more run of the leaf"""
+    import ctypes as C
+    NAMES = ["clear+ticket", "B", "count", "B", "scan", "segment search", "output (per-wave segments)", "-", "-", "loop", "-", "buckets"]
+    L.msd_debug_stamps.argtypes = [C.POINTER(C.c_uint64)]
+    buf = (C.c_uint64 * 32)()
+    L.msd_debug_stamps(buf)
+    ctx.merge_buckets(arrived, counts, base, 16, 0, work, n)
+    torch.cuda.synchronize()
+    L.msd_debug_stamps(buf)
+    out = {}
+    for wv, label in ((0, "wave0"), (1, "last_wave")):
+        v = [int(buf[wv * 16 + i]) for i in range(12)]
+        bk = max(1, v[11])
+        out[label] = {f"{i}:{NAMES[i]}": round(v[i] / bk) for i in range(11)}
+        out[label]["cycles_per_bucket"] = round(sum(v[:11]) / bk)
+        out[label]["buckets"] = v[11]
+    return out
+
+
 for it in range(3):
-    # keys of ONE rank's range (top log2(G) bits fixed) in the order the all-to-all delivers them: G sources, each with
-    # its `per` buckets in order.  Made from a top-digit pass over the rank's own uniform keys, cut into G parts per bucket.
+    # ---- before the exchange: the rank's own shard, uniform over all 32 bits
     ctx.gen_uniform_u32(keys, seed=it)
-    keys &= (1 << (32 - (G.bit_length() - 1))) - 1 if G > 1 else -1
-    t_part = timed(lambda: ctx.partition(keys, 24, 8))
+    note("fine: order the shard by its top 16 bits", timed(lambda: ctx.sort_top(keys, 16)))
+    note("fine: 65536 bucket boundaries", timed(lambda: ctx.bucket_bounds(keys, 16, 65536)))
+    ctx.gen_uniform_u32(keys, seed=it)
+    note("coarse: top-digit pass", timed(lambda: ctx.partition(keys, 24, 8)))
+
+    # ---- after the exchange, fine: N sources, each n / N keys of this rank's range ordered by their top 16 bits
+    ctx.gen_uniform_u32(keys, seed=100 + it)
+    if G > 1:
+        keys &= (1 << (32 - lg)) - 1                              # rank 0's range: 16-bit prefixes [0, 65536 / N)
+    c0 = ctx.check(keys)
+    a = arrived[:n]
+    a.copy_(keys)
+    chunk = n // G
+    rows, base = [], []
+    for s in range(G):
+        part = a[s * chunk:(s + 1) * chunk]
+        ctx.sort_top(part, 16)
+        b = ctx.bucket_bounds(part, 16, nbl)
+        rows.append(b[1:] - b[:-1])
+        base.append(s * chunk)
+    counts = torch.stack(rows).contiguous()
+    work.fill_(-1)
+    note("fine: counting leaf over the arrived extents", timed(lambda: ctx.merge_buckets(arrived, counts, base, 16, 0, work, n)))
+    c1 = ctx.check(work)
+    assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
+    rejected = ctx.stats().get("merge_rejected", 0)
+    if hasattr(L, "msd_debug_stamps") and it == 2:
+        stamps = read_stamps()
+
+    # ---- after the exchange, coarse (round 2): per source its 256 / N top-digit buckets in order
+    ctx.partition(keys, 24, 8)
     cnt = ctx.partition(keys, 24, 8).cpu().numpy()[:per]           # (idempotent: the keys are partitioned already)
     mine = [[int(c) // G + (int(c) % G if s == G - 1 else 0) for c in cnt] for s in range(G)]
     src_off, dst_off, lens, seg_off = bucket_major(mine)
-    ctx.gather_runs(arrived, keys, dst_off, src_off, lens)          # bucket-major -> source-major: "as it arrived"
-    c0 = ctx.check(keys)
-    t_gather = timed(lambda: ctx.gather_runs(work, arrived, src_off, dst_off, lens))
-    t_seg = timed(lambda: ctx.sort_segments(work, seg_off, 24))
-    t_legacy = timed(lambda: ctx.sort_u32(arrived, end_bit=32 - (G.bit_length() - 1)))
-    c1, c2 = ctx.check(work), ctx.check(arrived)
-    assert c1[0] == 0 and c1[1:] == c0[1:] and c2[0] == 0 and c2[1:] == c0[1:], (c0, c1, c2)
-    res["ms"] = {"top-digit pass before the exchange": round(t_part, 3), "gather runs bucket-major": round(t_gather, 3),
-                 "segmented sort on 24 bits": round(t_seg, 3), "replaced: sort on %d bits" % (32 - (G.bit_length() - 1)): round(t_legacy, 3)}
-res["local_ms_per_step"] = round(sum(v for k, v in res["ms"].items() if not k.startswith("replaced")), 3)
-res["local_ms_per_step_before"] = round(res["ms"]["top-digit pass before the exchange"] + [v for k, v in res["ms"].items() if k.startswith("replaced")][0], 3)
-print(json.dumps(res))
+    ctx.gather_runs(a, keys, dst_off, src_off, lens)                # bucket-major -> source-major: "as it arrived"
+    note("coarse: gather runs bucket-major", timed(lambda: ctx.gather_runs(work, a, src_off, dst_off, lens)))
+    note("coarse: segmented sort on 24 bits", timed(lambda: ctx.sort_segments(work, seg_off, 24)))
+    note("coarse, in place: sort on %d bits" % (32 - lg), timed(lambda: ctx.sort_u32(a, end_bit=32 - lg)))
+    c2, c3 = ctx.check(work), ctx.check(a)
+    assert c2[0] == 0 and c2[1:] == c0[1:] and c3[0] == 0 and c3[1:] == c0[1:], (c0, c2, c3)
+
+ms = {k: round(v, 3) for k, v in best.items()}
+fine_pre = ms["fine: order the shard by its top 16 bits"] + ms["fine: 65536 bucket boundaries"]
+fine_post = ms["fine: counting leaf over the arrived extents"]
+coarse_post = min(ms["coarse: gather runs bucket-major"] + ms["coarse: segmented sort on 24 bits"], ms["coarse, in place: sort on %d bits" % (32 - lg)])
+print(json.dumps({"ranks": G, "keys_per_rank": n, "ms_best_of_3": ms,
+                  "fine": {"pre_ms": round(fine_pre, 3), "post_ms": round(fine_post, 3), "local_ms_per_step": round(fine_pre + fine_post, 3),
+                           "merge_rejected_buckets": rejected},
+                  "coarse": {"pre_ms": ms["coarse: top-digit pass"], "post_ms": round(coarse_post, 3),
+                             "local_ms_per_step": round(ms["coarse: top-digit pass"] + coarse_post, 3)},
+                  **({"stamps_merge_count_kernel": stamps} if stamps else {})}))
