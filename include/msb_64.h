@@ -29,8 +29,11 @@
  *   - the phases reported are the GPU pipeline's: times[0] host-to-device staging (pinned,
  *     chunked, several copy streams), [1..7] the device phases (every device phase has a slot:
  *     they add up to the device time), [8] device-to-host staging, [9] the whole call.
- *   - arrays that do not fit the device memory: nothing is sorted, a message goes to stderr,
- *     times[] come back zero and msb_64_last_error() says why (void API, no abort).
+ *   - out of device memory (for the two arrays, or for the sort's workspace): nothing is sorted, the
+ *     caller's arrays are untouched, a message goes to stderr, times[] come back zero and
+ *     msb_64_last_error() says why.  sort() is void, as in the reference: a caller MUST look at
+ *     msb_64_last_error() after sort() (empty string = sorted) -- or set MSB_64_ABORT_ON_ERROR=1 in the
+ *     environment to get the reference's behaviour (it would have died in an assert) instead.
  */
 #ifndef MSB_64_H_HIP_
 #define MSB_64_H_HIP_
@@ -47,7 +50,8 @@ void sort(uint64_t **keys, uint64_t **rids, uint64_t *size,
 	  int threads, int numa, double fudge,
 	  char **description, uint64_t *times);
 
-/* empty string after a successful sort(), else why the last one did nothing (no counterpart in the reference) */
+/* empty string after a successful sort(), else why the last one did nothing (no counterpart in the reference).
+ * Check it after every sort(): the call is void and returns normally when the device memory does not suffice. */
 const char *msb_64_last_error(void);
 
 /* reference: include/msb_64.h:41, src/msb_64.c:111-115 (64-byte aligned, free()) */

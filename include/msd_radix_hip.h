@@ -49,6 +49,8 @@ enum {
 int msd_create(msd_ctx **ctx, int device, void *stream);
 int msd_destroy(msd_ctx *ctx);
 int msd_set_stream(msd_ctx *ctx, void *stream);
+void *msd_get_stream(const msd_ctx *ctx); /* the hipStream_t the context launches on */
+int msd_get_device(const msd_ctx *ctx);
 /* Pre-allocate the workspace for sorting n elements of key_bytes (+val_bytes)
  * so that the first timed call does not allocate. */
 int msd_reserve(msd_ctx *ctx, uint64_t n, int key_bytes, int val_bytes);
@@ -166,6 +168,14 @@ int msd_sample_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint64_t m,
 int msd_splitters_u32(msd_ctx *ctx, const uint32_t *d_sorted_sample, uint64_t m, unsigned parts, uint32_t *d_delims);
 int msd_partition_by_splitters_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, const uint32_t *d_delims,
 				   unsigned parts, uint64_t *d_count);
+/* the same for what the reference itself sorts: 64-bit keys, alone or with their rids (its sample, its delimiters and
+ * its range function all work on 64-bit keys, src/msb_64.c:1511-1564, :1304-1322, :188-204) */
+int msd_sample_u64(msd_ctx *ctx, const uint64_t *d_keys, uint64_t n, uint64_t m, uint64_t seed, uint64_t *d_sample);
+int msd_splitters_u64(msd_ctx *ctx, const uint64_t *d_sorted_sample, uint64_t m, unsigned parts, uint64_t *d_delims);
+int msd_partition_by_splitters_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, const uint64_t *d_delims,
+				   unsigned parts, uint64_t *d_count);
+int msd_partition_by_splitters_pairs_u64(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n,
+					 const uint64_t *d_delims, unsigned parts, uint64_t *d_count);
 
 /* Verifier, the device form of check() (src/msb_64.c:2432-2505): counts order
  * violations (key[i] < key[i-1]) and, when d_rids != NULL, key != rid

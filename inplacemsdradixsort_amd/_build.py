@@ -16,8 +16,12 @@ LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
 # diagnostic build with in-kernel cycle stamps (tools/variant_run.py); never what tests or bench.py load
 STAMPS_LIB = os.path.join(HERE, "libinpmsdradix_hip_stamps.so")
 SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
-DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_count16.hpp", "msd_regpart.hpp", "msd_bigcount.hpp", os.path.join("..", "..", "include", "msd_radix_hip.h"),
-                  os.path.join("..", "..", "include", "msb_64.h")]
+DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_count16.hpp", "msd_merge16.hpp", "msd_regpart.hpp", "msd_bigcount.hpp",
+                  os.path.join("..", "..", "include", "msd_radix_hip.h"), os.path.join("..", "..", "include", "msb_64.h")]
+# the multi-GPU entry points (include/msd_sharded_hip.h): a library of its own, linked against the one above and RCCL
+RCCL_LIB = os.path.join(HERE, "libinpmsdradix_hip_rccl.so")
+RCCL_SOURCES = ["msd_sharded.hip"]
+RCCL_DEPS = RCCL_SOURCES + [os.path.join("..", "..", "include", "msd_sharded_hip.h"), os.path.join("..", "..", "include", "msd_radix_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
          "-Wno-unused-result", "-pthread"]
 
@@ -29,11 +33,37 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built")
 
 
+def _rocm_lib() -> str:
+    return os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")
+
+
 def stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
+
+
+def rccl_stale() -> bool:
+    if not os.path.exists(RCCL_LIB):
+        return True
+    t = os.path.getmtime(RCCL_LIB)
+    return os.path.getmtime(LIB) > t or any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in RCCL_DEPS)
+
+
+def build_rccl(force: bool = False, verbose: bool = False) -> str:
+    """libinpmsdradix_hip_rccl.so: csrc/msd_sharded.hip against libinpmsdradix_hip.so (found next to it at run time,
+    $ORIGIN) and librccl.  hipcc cross-compiles and links it without a GPU; RCCL is only needed when it is loaded."""
+    build(force=False)
+    if not force and not rccl_stale():
+        return RCCL_LIB
+    cmd = [_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in RCCL_SOURCES], "-o", RCCL_LIB + ".tmp",
+           "-L" + HERE, "-l:libinpmsdradix_hip.so", "-L" + _rocm_lib(), "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + _rocm_lib()]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(RCCL_LIB + ".tmp", RCCL_LIB)
+    return RCCL_LIB
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -13,13 +13,14 @@ from . import _build
 
 # every symbol include/msd_radix_hip.h and include/msb_64.h declare
 EXPORTS = [
-    "msd_create", "msd_destroy", "msd_set_stream", "msd_reserve", "msd_workspace_bytes",
+    "msd_create", "msd_destroy", "msd_set_stream", "msd_get_stream", "msd_get_device", "msd_reserve", "msd_workspace_bytes",
     "msd_last_error", "msd_version",
     "msd_sort_u32", "msd_sort_u64", "msd_sort_pairs_u64",
     "msd_sort_u32_bits", "msd_sort_u64_bits", "msd_sort_pairs_u64_bits",
     "msd_histogram_u32", "msd_histogram_u64", "msd_exclusive_scan_u64",
     "msd_partition_u32", "msd_partition_u64", "msd_partition_pairs_u64",
     "msd_sample_u32", "msd_splitters_u32", "msd_partition_by_splitters_u32",
+    "msd_sample_u64", "msd_splitters_u64", "msd_partition_by_splitters_u64", "msd_partition_by_splitters_pairs_u64",
     "msd_sort_u32_top", "msd_sort_u64_top", "msd_sort_pairs_u64_top", "msd_bucket_bounds_u32", "msd_bucket_bounds_u64", "msd_merge_buckets_u32",
     "msd_sort_u32_segments", "msd_sort_u64_segments", "msd_sort_pairs_u64_segments", "msd_gather_runs_u32", "msd_gather_runs_u64",
     "msd_check_u32", "msd_check_u64",
@@ -30,7 +31,12 @@ EXPORTS = [
     "sort", "mamalloc", "check", "msb_64_last_error",
 ]
 
+# every symbol include/msd_sharded_hip.h declares (libinpmsdradix_hip_rccl.so)
+RCCL_EXPORTS = ["msd_shard_create", "msd_shard_destroy", "msd_shard_rank", "msd_shard_world", "msd_shard_last_error",
+                "msd_sort_u32_sharded", "msd_sort_pairs_u64_sharded", "msd_sort_u32_multi"]
+
 _lib = None
+_rccl = None
 
 
 class MsdPlan(C.Structure):
@@ -60,6 +66,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.msd_create.argtypes = [C.POINTER(_vp), C.c_int, _vp]
     L.msd_destroy.argtypes = [_vp]
     L.msd_set_stream.argtypes = [_vp, _vp]
+    L.msd_get_stream.argtypes = [_vp]
+    L.msd_get_stream.restype = _vp
+    L.msd_get_device.argtypes = [_vp]
     L.msd_reserve.argtypes = [_vp, _u64, C.c_int, C.c_int]
     L.msd_workspace_bytes.argtypes = [_vp]
     L.msd_workspace_bytes.restype = _u64
@@ -81,6 +90,10 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.msd_sample_u32.argtypes = [_vp, _vp, _u64, _u64, _u64, _vp]
     L.msd_splitters_u32.argtypes = [_vp, _vp, _u64, C.c_uint, _vp]
     L.msd_partition_by_splitters_u32.argtypes = [_vp, _vp, _u64, _vp, C.c_uint, _vp]
+    L.msd_sample_u64.argtypes = [_vp, _vp, _u64, _u64, _u64, _vp]
+    L.msd_splitters_u64.argtypes = [_vp, _vp, _u64, C.c_uint, _vp]
+    L.msd_partition_by_splitters_u64.argtypes = [_vp, _vp, _u64, _vp, C.c_uint, _vp]
+    L.msd_partition_by_splitters_pairs_u64.argtypes = [_vp, _vp, _vp, _u64, _vp, C.c_uint, _vp]
     for f in ("msd_sort_u32_segments", "msd_sort_u64_segments"):
         getattr(L, f).argtypes = [_vp, _vp, _u64, _u64p, C.c_uint32, C.c_int]
     L.msd_sort_pairs_u64_segments.argtypes = [_vp, _vp, _vp, _u64, _u64p, C.c_uint32, C.c_int]
@@ -113,9 +126,36 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.sort.argtypes = [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int, C.c_double,
                        C.POINTER(C.c_char_p), _u64p]
     L.sort.restype = None
+    L.msb_64_last_error.restype = C.c_char_p
     L.mamalloc.argtypes = [C.c_size_t]
     L.mamalloc.restype = _vp
     L.check.argtypes = [C.POINTER(_u64p), C.POINTER(_u64p), _u64p, C.c_int, C.c_int]
     L.check.restype = _u64
     _lib = L
+    return L
+
+
+def load_rccl(build_if_missing: bool = True) -> C.CDLL:
+    """The multi-GPU entry points (include/msd_sharded_hip.h).  Loading it loads RCCL (the process's own if torch has
+    loaded one: same soname)."""
+    global _rccl
+    if _rccl is not None:
+        return _rccl
+    load(build_if_missing)
+    if build_if_missing and _build.rccl_stale():
+        _build.build_rccl()
+    if not os.path.exists(_build.RCCL_LIB):
+        raise RuntimeError(f"{_build.RCCL_LIB} is missing: run inplacemsdradixsort_amd._build.build_rccl()")
+    L = C.CDLL(_build.RCCL_LIB)
+    _vpp = C.POINTER(_vp)
+    L.msd_shard_create.argtypes = [_vpp, _vp, _vp]
+    L.msd_shard_destroy.argtypes = [_vp]
+    L.msd_shard_rank.argtypes = [_vp]
+    L.msd_shard_world.argtypes = [_vp]
+    L.msd_shard_last_error.argtypes = [_vp]
+    L.msd_shard_last_error.restype = C.c_char_p
+    L.msd_sort_u32_sharded.argtypes = [_vp, _vp, _u64, _vp, _u64, _vp, _u64, C.c_int, _vpp, _u64p]
+    L.msd_sort_pairs_u64_sharded.argtypes = [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vpp, _vpp, _u64p]
+    L.msd_sort_u32_multi.argtypes = [C.c_int, C.POINTER(C.c_int), _vpp, _u64p, _vpp, _u64, _vpp, _u64, C.c_int, _vpp, _u64p]
+    _rccl = L
     return L

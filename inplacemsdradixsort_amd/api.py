@@ -178,28 +178,41 @@ class MsdContext:
                    self._u64arr(src_off), self._u64arr(dst_off), self._u64arr(lens), len(lens)))
 
     # ---- splitter service (reference: src/msb_64.c:1511-1521, :1304-1322, :188-204)
-    def sample_u32(self, keys, m: int, seed: int = 0x5EED0007):
-        """m keys drawn from the (unsorted) tensor at pseudo-random positions mulhi(splitmix64(seed + i), n)."""
+    def sample(self, keys, m: int, seed: int = 0x5EED0007):
+        """m keys drawn from the (unsorted) tensor at pseudo-random positions mulhi(splitmix64(seed + i), n);
+        u32 (int32 tensor) or u64 (int64 tensor) keys."""
         torch = _torch()
-        out = torch.empty(m, dtype=torch.int32, device=keys.device)
-        self._ok(self._L.msd_sample_u32(self._h, self._ptr(keys, 4), keys.numel(), m, seed, C.c_void_p(out.data_ptr())))
+        es = keys.element_size()
+        out = torch.empty(m, dtype=keys.dtype, device=keys.device)
+        f = self._L.msd_sample_u32 if es == 4 else self._L.msd_sample_u64
+        self._ok(f(self._h, self._ptr(keys, es), keys.numel(), m, seed, C.c_void_p(out.data_ptr())))
         return out
 
-    def splitters_u32(self, sorted_sample, parts: int):
-        """parts-1 equi-depth delimiters (u32 bit patterns in an int32 tensor) with the reference's duplicate rule."""
+    def splitters(self, sorted_sample, parts: int):
+        """parts-1 equi-depth delimiters (bit patterns in a tensor of the sample's dtype) with the reference's duplicate rule."""
         torch = _torch()
-        out = torch.empty(max(parts - 1, 0), dtype=torch.int32, device=sorted_sample.device)
-        self._ok(self._L.msd_splitters_u32(self._h, self._ptr(sorted_sample, 4), sorted_sample.numel(), parts,
-                                           C.c_void_p(out.data_ptr())))
+        es = sorted_sample.element_size()
+        out = torch.empty(max(parts - 1, 0), dtype=sorted_sample.dtype, device=sorted_sample.device)
+        f = self._L.msd_splitters_u32 if es == 4 else self._L.msd_splitters_u64
+        self._ok(f(self._h, self._ptr(sorted_sample, es), sorted_sample.numel(), parts, C.c_void_p(out.data_ptr())))
         return out
 
-    def partition_by_splitters(self, keys, delims, parts: int):
-        """One in-place pass: range p = keys in (delims[p-1], delims[p]]; returns the range sizes (int64 tensor)."""
+    sample_u32 = sample          # (round 2's names)
+    splitters_u32 = splitters
+
+    def partition_by_splitters(self, keys, delims, parts: int, rids=None):
+        """One in-place pass: range p = keys in (delims[p-1], delims[p]] (rids move with their keys); returns the range
+        sizes (int64 tensor)."""
         torch = _torch()
+        es = keys.element_size()
         cnt = torch.zeros(parts, dtype=torch.int64, device=keys.device)
-        dp = self._ptr(delims, 4) if parts > 1 else C.c_void_p(0)
-        self._ok(self._L.msd_partition_by_splitters_u32(self._h, self._ptr(keys, 4), keys.numel(), dp, parts,
-                                                        C.c_void_p(cnt.data_ptr())))
+        dp = self._ptr(delims, es) if parts > 1 else C.c_void_p(0)
+        if rids is not None:
+            self._ok(self._L.msd_partition_by_splitters_pairs_u64(self._h, self._ptr(keys, 8), self._ptr(rids, 8), keys.numel(), dp, parts,
+                                                                  C.c_void_p(cnt.data_ptr())))
+        else:
+            f = self._L.msd_partition_by_splitters_u32 if es == 4 else self._L.msd_partition_by_splitters_u64
+            self._ok(f(self._h, self._ptr(keys, es), keys.numel(), dp, parts, C.c_void_p(cnt.data_ptr())))
         return cnt
 
     def check(self, keys, rids=None) -> Tuple[int, int, int]:
@@ -255,6 +268,77 @@ class MsdContext:
         return out
 
 
+class MsdShard:
+    """One rank of a sharded sort behind the C ABI (include/msd_sharded_hip.h): RCCL is called from C, no
+    torch.distributed on the data path.  ``nccl_comm``: the address of the caller's ncclComm_t -- e.g.
+    :func:`torch_nccl_comm` for the process group torch.distributed has set up -- or None for a single rank."""
+
+    def __init__(self, ctx: MsdContext, nccl_comm: Optional[int] = None):
+        self._L = _lib.load_rccl()
+        self.ctx = ctx
+        h = C.c_void_p()
+        rc = self._L.msd_shard_create(C.byref(h), ctx._h, C.c_void_p(nccl_comm or 0))
+        if rc != 0 or not h:
+            raise MsdError(f"msd_shard_create failed with {rc}")
+        self._h = h
+        self.rank = int(self._L.msd_shard_rank(h))
+        self.world = int(self._L.msd_shard_world(h))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._L.msd_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ok(self, rc: int) -> None:
+        if rc == -5:
+            from .dist import ReceiveOverflow
+            raise ReceiveOverflow(self._L.msd_shard_last_error(self._h).decode())
+        if rc != 0:
+            raise MsdError(f"error {rc}: {self._L.msd_shard_last_error(self._h).decode()}")
+
+    def sort_u32(self, keys, recv, work=None, scheme: Optional[str] = None):
+        """``msd_sort_u32_sharded``: returns this rank's sorted key range -- a view of ``work`` (fine scheme), ``recv``
+        (coarse) or ``keys`` (single rank)."""
+        p = self.ctx._ptr
+        out, n_out = C.c_void_p(), C.c_uint64()
+        sc = {None: 0, "fine": 1, "coarse": 2}[scheme]
+        self._ok(self._L.msd_sort_u32_sharded(self._h, p(keys, 4), keys.numel(), p(recv, 4) if recv is not None else None,
+                                              recv.numel() if recv is not None else 0, p(work, 4) if work is not None else None,
+                                              work.numel() if work is not None else 0, sc, C.byref(out), C.byref(n_out)))
+        for t in (work, recv, keys):
+            if t is not None and t.data_ptr() == out.value:
+                return t[:n_out.value]
+        raise MsdError("msd_sort_u32_sharded returned an unknown buffer")
+
+    def sort_pairs_u64(self, keys, rids, recv_keys, recv_rids):
+        p = self.ctx._ptr
+        ok_, or_, n_out = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        cap = min(recv_keys.numel(), recv_rids.numel()) if recv_keys is not None else 0
+        self._ok(self._L.msd_sort_pairs_u64_sharded(self._h, p(keys, 8), p(rids, 8), keys.numel(),
+                                                    p(recv_keys, 8) if recv_keys is not None else None,
+                                                    p(recv_rids, 8) if recv_rids is not None else None, cap,
+                                                    C.byref(ok_), C.byref(or_), C.byref(n_out)))
+        if ok_.value == keys.data_ptr():
+            return keys[:n_out.value], rids[:n_out.value]
+        return recv_keys[:n_out.value], recv_rids[:n_out.value]
+
+
+def torch_nccl_comm(device: int) -> int:
+    """Address of the ncclComm_t (RCCL) behind torch.distributed's default process group on ``device`` (backend "nccl";
+    the communicator exists once a collective has run on it)."""
+    import torch
+    import torch.distributed as dist
+    pg = dist.distributed_c10d._get_default_group()
+    be = pg._get_backend(torch.device("cuda", device))
+    return int(be._comm_ptr())
+
+
 def plan_first_round(n: int, key_bytes: int = 4, val_bytes: int = 0, end_bit: Optional[int] = None,
                      compute_units: int = 256) -> Dict[str, int]:
     """Host-only pass planner (the counterpart of the reference's schedule_passes,
@@ -296,6 +380,15 @@ def sort(keys: Sequence[np.ndarray], rids: Sequence[np.ndarray], size: Sequence[
     for a in list(keys) + list(rids):
         if a.dtype != np.uint64 or not a.flags.c_contiguous:
             raise MsdError("arrays must be contiguous uint64")
+    # size[] is REWRITTEN by the call (the reference does the same, src/msb_64.c:2180): it must be writable ...
+    if isinstance(size, tuple) or (isinstance(size, np.ndarray) and not size.flags.writeable):
+        raise MsdError("size must be a mutable sequence: sort() rewrites it")
+    # ... and with fudge > 1 an array may come back with up to size[a] * fudge tuples (the capacity the reference
+    # requires of the caller, :1574-1578): the arrays must have that room
+    for a in range(numa):
+        cap = int(float(size[a]) * fudge) if fudge > 1.0 else int(size[a])
+        if keys[a].size < cap or rids[a].size < cap:
+            raise MsdError(f"array {a} holds {min(keys[a].size, rids[a].size)} elements but needs room for int(size * fudge) = {cap}")
     KA = (_u64p * numa)(*[a.ctypes.data_as(_u64p) for a in keys[:numa]])
     RA = (_u64p * numa)(*[a.ctypes.data_as(_u64p) for a in rids[:numa]])
     sz = np.array(list(size)[:numa], dtype=np.uint64)
@@ -303,7 +396,10 @@ def sort(keys: Sequence[np.ndarray], rids: Sequence[np.ndarray], size: Sequence[
     times = np.zeros(10, dtype=np.uint64)
     L.sort(KA, RA, sz.ctypes.data_as(_u64p), threads, numa, fudge, desc, times.ctypes.data_as(_u64p))
     for i, s in enumerate(sz):
-        size[i] = int(s) if isinstance(size, list) else size[i]
+        size[i] = int(s)
+    err = L.msb_64_last_error()
+    if err:
+        raise MsdError(err.decode())
     return [d.decode() if d is not None else None for d in desc], times
 
 

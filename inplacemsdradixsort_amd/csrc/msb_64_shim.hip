@@ -208,18 +208,27 @@ void sort(uint64_t **keys, uint64_t **rids, uint64_t *size, int threads, int num
 		uint64_t *dk = nullptr, *dr = nullptr;
 		HIP_OR_DIE(hipSetDevice(0));
 		uint64_t t0 = now_us();
-		if (hipMalloc((void **)&dk, total * sizeof(uint64_t)) != hipSuccess ||
-		    hipMalloc((void **)&dr, total * sizeof(uint64_t)) != hipSuccess) {
-			// not a contract violation: the data stay as they are, the caller can ask why (void API, like the reference's)
+		// Out of device memory -- for the two arrays or, further down, for the sort's workspace -- is ONE case with ONE
+		// policy: not a contract violation, so nothing is sorted, the caller's arrays stay as they are, times[] come back
+		// zero and msb_64_last_error() says why (the API is void, like the reference's).  A caller that would rather stop
+		// than go on with unsorted data -- the reference would have died in an assert -- sets MSB_64_ABORT_ON_ERROR=1.
+		auto out_of_memory = [&](const char *what) {
 			if (dk) (void)hipFree(dk);
+			if (dr) (void)hipFree(dr);
 			(void)hipGetLastError();
-			g_last_error = "sort(): the arrays do not fit the device memory; nothing was sorted";
+			g_last_error = std::string("sort(): ") + what + "; nothing was sorted";
+			const char *ab = getenv("MSB_64_ABORT_ON_ERROR");
+			if (ab && atoi(ab) != 0) die(g_last_error.c_str(), nullptr);
 			fprintf(stderr, "inpmsdradix_hip: %s\n", g_last_error.c_str());
 			if (times) memset(times, 0, 10 * sizeof(uint64_t));
 			if (description) {
 				for (int i = 0; i < 10; ++i) description[i] = const_cast<char *>(kLabels[i]);
 				description[10] = nullptr;
 			}
+		};
+		if (hipMalloc((void **)&dk, total * sizeof(uint64_t)) != hipSuccess ||
+		    hipMalloc((void **)&dr, total * sizeof(uint64_t)) != hipSuccess) {
+			out_of_memory("the arrays do not fit the device memory");
 			return;
 		}
 		std::vector<Piece> pieces;
@@ -234,6 +243,11 @@ void sort(uint64_t **keys, uint64_t **rids, uint64_t *size, int threads, int num
 		tm[0] = now_us() - t0;
 		msd_set_profiling(ctx, 1);
 		int rc = msd_sort_pairs_u64(ctx, dk, dr, total);
+		if (rc == MSD_ENOMEM) { // (the caller's arrays have not been touched yet: only copies went to the device)
+			msd_set_profiling(ctx, 0);
+			out_of_memory("no device memory for the sort's workspace");
+			return;
+		}
 		if (rc != MSD_OK) die("sort(): device sort failed", msd_last_error(ctx));
 		for (int i = 0; i < msd_phase_count(ctx); ++i) tm[slot_of(msd_phase_name(ctx, i))] += (uint64_t)msd_phase_us(ctx, i);
 		msd_set_profiling(ctx, 0);

@@ -18,8 +18,9 @@ using namespace msd;
 
 #define MSD_VERSION "inplacemsdradixsort_amd 0.2 (gfx950)"
 
-// range partitioning (classify_kernel<.., true>) is built for the key type the multi-GPU path shards: u32 keys
-template <typename K, typename V> constexpr bool kHasRange = std::is_same<K, uint32_t>::value && !has_val<V>::value;
+// range partitioning (classify_kernel<.., true>) is built for every element type: the multi-GPU path shards u32 keys,
+// u64 keys and the reference's own (u64 key, u64 rid) tuples by sampled splitters when the keys are skewed
+template <typename K, typename V> constexpr bool kHasRange = true;
 
 struct PhaseRec {
 	const char *name;
@@ -252,8 +253,16 @@ static void plan_round(const std::vector<Segment> &segs, uint64_t small_max, int
 	for (auto &s : segs) total += s.count;
 	rp.round_keys = total;
 	// stripe length: enough stripes to fill the chip a few times over, whole tiles
-	static const int want_mul = getenv("MSD_STRIPE_WANT") ? atoi(getenv("MSD_STRIPE_WANT")) : 4;         // (experiments)
-	static const int cap_log = getenv("MSD_STRIPE_CAP_LOG") ? atoi(getenv("MSD_STRIPE_CAP_LOG")) : 20;
+	// (experiment knobs, compiled in with -DMSD_STRIPE_WANT= / -DMSD_STRIPE_CAP_LOG= for variant builds only:
+	// tools/variant_run.py.  They used to be read from the environment, unchecked, by every context of the process.)
+#ifndef MSD_STRIPE_WANT
+#define MSD_STRIPE_WANT 4
+#endif
+#ifndef MSD_STRIPE_CAP_LOG
+#define MSD_STRIPE_CAP_LOG 20
+#endif
+	static_assert(MSD_STRIPE_WANT >= 1 && MSD_STRIPE_WANT <= 64 && MSD_STRIPE_CAP_LOG >= 12 && MSD_STRIPE_CAP_LOG <= 20, "stripe geometry knobs out of range (a stripe has at most 2^20 elements)");
+	constexpr int want_mul = MSD_STRIPE_WANT, cap_log = MSD_STRIPE_CAP_LOG;
 	uint64_t want = std::max<uint64_t>(1, (uint64_t)sm_count * want_mul);
 	uint64_t slen = (total + want - 1) / want;
 	slen = std::max<uint64_t>(slen, 4 * T);
@@ -1234,9 +1243,16 @@ int msd_create(msd_ctx **out, int device, void *stream)
 	}
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->sm_count = prop.multiProcessorCount;
-	if (getenv("MSD_DIRECT")) c->direct_mode = atoi(getenv("MSD_DIRECT")); // A/B switches for benchmarks
-	if (getenv("MSD_REGPART")) c->regpart = atoi(getenv("MSD_REGPART")) != 0;
-	if (getenv("MSD_COUNT16")) c->count16 = atoi(getenv("MSD_COUNT16")); // 0 off, 1 by segment size, 2 always
+	// A/B switches for benchmarks: the same knobs as msd_set_option, through the same range checks (an out-of-range
+	// value is reported and ignored)
+	for (const char *name : { "direct_mode", "regpart", "count16" }) {
+		const char *env = !strcmp(name, "direct_mode") ? "MSD_DIRECT" : !strcmp(name, "regpart") ? "MSD_REGPART" : "MSD_COUNT16";
+		const char *v = getenv(env);
+		if (!v) continue;
+		char *end = nullptr;
+		const long x = strtol(v, &end, 10);
+		if (end == v || *end || msd_set_option(c, name, x) != MSD_OK) fprintf(stderr, "msd_create: ignoring %s=%s\n", env, v);
+	}
 	int rc = set_lds_attrs<uint32_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, NoVal>(c);
 	if (!rc) rc = set_lds_attrs<uint64_t, uint64_t>(c);
@@ -1270,6 +1286,9 @@ int msd_set_stream(msd_ctx *c, void *stream)
 	c->stream = (hipStream_t)stream;
 	return MSD_OK;
 }
+
+void *msd_get_stream(const msd_ctx *c) { return c ? (void *)c->stream : nullptr; }
+int msd_get_device(const msd_ctx *c) { return c ? c->device : -1; }
 
 int msd_reserve(msd_ctx *c, uint64_t n, int key_bytes, int val_bytes)
 {
@@ -1322,18 +1341,21 @@ int msd_sort_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n) { retur
 int msd_partition_u32(msd_ctx *c, uint32_t *k, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
 {
 	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
 	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
 	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, 32, true, shift, rb, cnt);
 }
 int msd_partition_u64(msd_ctx *c, uint64_t *k, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
 {
 	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
 	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
 	return sort_impl<uint64_t, NoVal>(c, k, nullptr, n, 64, true, shift, rb, cnt);
 }
 int msd_partition_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, unsigned shift, unsigned rb, uint64_t *cnt)
 {
 	if (!c) return MSD_EINVAL;
+	HIPCHK(c, hipSetDevice(c->device));
 	if (cnt && rb <= 8) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) << rb, c->stream));
 	return sort_impl<uint64_t, uint64_t>(c, k, r, n, 64, true, shift, rb, cnt);
 }
@@ -1509,44 +1531,75 @@ int msd_gather_runs_u64(msd_ctx *c, uint64_t *dst, const uint64_t *src, const ui
 
 // ---- splitter service (reference: sampling src/msb_64.c:1511-1521, extract_delimiters :1304-1322, range function :188-204)
 
-int msd_sample_u32(msd_ctx *c, const uint32_t *k, uint64_t n, uint64_t m, uint64_t seed, uint32_t *out)
+} // extern "C"
+
+template <typename K> static int sample_impl(msd_ctx *c, const K *k, uint64_t n, uint64_t m, uint64_t seed, K *out)
 {
 	if (!c) return MSD_EINVAL;
 	if (m && (!k || !out || n == 0)) return fail(c, MSD_EINVAL, "sample: null pointer or empty input");
 	HIPCHK(c, hipSetDevice(c->device));
 	if (m == 0) return MSD_OK;
 	const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 8, (m + 255) / 256);
-	hipLaunchKernelGGL((sample_kernel<uint32_t>), dim3(grid), dim3(256), 0, c->stream, k, n, m, seed, out);
+	hipLaunchKernelGGL((sample_kernel<K>), dim3(grid), dim3(256), 0, c->stream, k, n, m, seed, out);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }
 
-int msd_splitters_u32(msd_ctx *c, const uint32_t *sorted_sample, uint64_t m, unsigned parts, uint32_t *delims)
+template <typename K> static int splitters_impl(msd_ctx *c, const K *sorted_sample, uint64_t m, unsigned parts, K *delims)
 {
 	if (!c) return MSD_EINVAL;
 	if (parts < 1 || parts > 256) return fail(c, MSD_EINVAL, "splitters: parts must be 1..256");
 	if (parts == 1) return MSD_OK;
 	if (!sorted_sample || !delims || m == 0) return fail(c, MSD_EINVAL, "splitters: null pointer or empty sample");
 	HIPCHK(c, hipSetDevice(c->device));
-	hipLaunchKernelGGL((splitters_kernel<uint32_t>), dim3(1), dim3(256), 0, c->stream, sorted_sample, m, parts, delims);
+	hipLaunchKernelGGL((splitters_kernel<K>), dim3(1), dim3(256), 0, c->stream, sorted_sample, m, parts, delims);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }
 
-int msd_partition_by_splitters_u32(msd_ctx *c, uint32_t *k, uint64_t n, const uint32_t *delims, unsigned parts, uint64_t *cnt)
+template <typename K, typename V>
+static int range_partition_impl(msd_ctx *c, K *k, uint64_t *r, uint64_t n, const K *delims, unsigned parts, uint64_t *cnt)
 {
 	if (!c) return MSD_EINVAL;
 	if (parts < 1 || parts > 256) return fail(c, MSD_EINVAL, "partition_by_splitters: parts must be 1..256");
 	if (parts > 1 && !delims) return fail(c, MSD_EINVAL, "partition_by_splitters: null delimiters");
-	if (cnt) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) * parts, c->stream));
-	if (parts == 1) { // one range: nothing moves
-		if (cnt) HIPCHK(c, hipMemcpy(cnt, &n, sizeof n, hipMemcpyHostToDevice));
+	HIPCHK(c, hipSetDevice(c->device));
+	if (parts == 1) { // one range: nothing moves; its size goes to the device on the context's stream (ordered with the caller's work there)
+		if (cnt) {
+			int rcp = pinned_reserve(c, 64);
+			if (rcp) return rcp;
+			HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
+			memcpy(c->pinned, &n, sizeof n);
+			HIPCHK(c, hipMemcpyAsync(cnt, c->pinned, sizeof n, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(c, hipStreamSynchronize(c->stream));
+		}
 		return MSD_OK;
 	}
+	if (cnt) HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(uint64_t) * parts, c->stream));
 	unsigned width = 1;
 	while ((1u << width) < parts) ++width;
 	// one in-place round whose buckets are the ranges (parts - 1 delimiters; the buckets beyond `parts` stay empty)
-	return sort_impl<uint32_t, NoVal>(c, k, nullptr, n, 32, true, 0, width, cnt, delims, parts - 1);
+	return sort_impl<K, V>(c, k, r, n, (int)sizeof(K) * 8, true, 0, width, cnt, delims, parts - 1);
+}
+
+extern "C" {
+
+int msd_sample_u32(msd_ctx *c, const uint32_t *k, uint64_t n, uint64_t m, uint64_t seed, uint32_t *out) { return sample_impl<uint32_t>(c, k, n, m, seed, out); }
+int msd_sample_u64(msd_ctx *c, const uint64_t *k, uint64_t n, uint64_t m, uint64_t seed, uint64_t *out) { return sample_impl<uint64_t>(c, k, n, m, seed, out); }
+int msd_splitters_u32(msd_ctx *c, const uint32_t *s, uint64_t m, unsigned parts, uint32_t *d) { return splitters_impl<uint32_t>(c, s, m, parts, d); }
+int msd_splitters_u64(msd_ctx *c, const uint64_t *s, uint64_t m, unsigned parts, uint64_t *d) { return splitters_impl<uint64_t>(c, s, m, parts, d); }
+int msd_partition_by_splitters_u32(msd_ctx *c, uint32_t *k, uint64_t n, const uint32_t *delims, unsigned parts, uint64_t *cnt)
+{
+	return range_partition_impl<uint32_t, NoVal>(c, k, nullptr, n, delims, parts, cnt);
+}
+int msd_partition_by_splitters_u64(msd_ctx *c, uint64_t *k, uint64_t n, const uint64_t *delims, unsigned parts, uint64_t *cnt)
+{
+	return range_partition_impl<uint64_t, NoVal>(c, k, nullptr, n, delims, parts, cnt);
+}
+int msd_partition_by_splitters_pairs_u64(msd_ctx *c, uint64_t *k, uint64_t *r, uint64_t n, const uint64_t *delims, unsigned parts, uint64_t *cnt)
+{
+	if (c && !r) return fail(c, MSD_EINVAL, "partition_by_splitters: null rids");
+	return range_partition_impl<uint64_t, uint64_t>(c, k, r, n, delims, parts, cnt);
 }
 
 } // extern "C"

@@ -390,15 +390,65 @@ class ShardedSorter:
         return len(self._pending)
 
 
+def _sort_sharded_sampled(engine, keys, rids, recv, recv_rids, dist, world: int, group, sample_per_rank: int, seed: int):
+    import torch
+    pairs = rids is not None
+    es = keys.element_size()
+
+    def local_sort(k, r):
+        if pairs:
+            engine.sort_pairs_u64(k, r)
+        elif es == 4:
+            engine.sort_u32(k)
+        else:
+            engine.sort_u64(k)
+
+    if world == 1:
+        local_sort(keys, rids)
+        return (keys, rids) if pairs else keys
+    if pairs and recv.numel() != recv_rids.numel():
+        raise ValueError("receive buffers for keys and rids differ in length")
+    n = keys.numel()
+    m = min(sample_per_rank, n)
+    mine = engine.sample(keys, m, seed + 7919 * _rank(dist, group))
+    # ranks may hold different numbers of keys: gather the sample sizes, then the (padded) samples
+    cnt = torch.tensor([m], dtype=torch.int64, device=keys.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    sizes = [int(c.item()) for c in cnts]
+    mmax = max(sizes)
+    pad = torch.zeros(max(mmax, 1), dtype=keys.dtype, device=keys.device)
+    pad[:m] = mine
+    allp = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(allp, pad, group=group)
+    sample = torch.cat([p[:s] for p, s in zip(allp, sizes)]).contiguous()
+    if sample.numel():
+        (engine.sort_u32 if es == 4 else engine.sort_u64)(sample)
+        delim = engine.splitters(sample, world)                         # [world-1] key bit patterns, on the device
+    else:
+        delim = torch.zeros(world - 1, dtype=keys.dtype, device=keys.device)
+    send = engine.partition_by_splitters(keys, delim, world, rids=rids) if pairs else engine.partition_by_splitters(keys, delim, world)
+    send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)   # int64[world]: range sizes, ranges contiguous
+    m_out = int(sum(got_l))
+    out = recv[:m_out]
+    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    out_r = None
+    if pairs:
+        out_r = recv_rids[:m_out]
+        dist.all_to_all_single(out_r, rids, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    local_sort(out, out_r)
+    return (out, out_r) if pairs else out
+
+
 def sort_sharded_u32_sampled(engine, keys, recv, dist, world: int, group=None, sample_per_rank: int = 65536,
                              seed: int = 0x5EED0007):
     """Skew-robust variant, the reference's own scheme (src/msb_64.c:1511-1564) with one range per rank:
 
       * every rank draws ``sample_per_rank`` keys at random from its UNSORTED shard
-        (``engine.sample_u32``: index = mulhi(rand64, n), :1511-1521) -- nothing is sorted before the exchange;
+        (``engine.sample``: index = mulhi(rand64, n), :1511-1521) -- nothing is sorted before the exchange;
       * the samples are all-gathered and sorted (``engine.sort_u32``, the reference sorts its sample with
         eight passes of partition_keys, :1526-1541);
-      * world-1 equi-depth delimiters with the reference's duplicate rule (``engine.splitters_u32``,
+      * world-1 equi-depth delimiters with the reference's duplicate rule (``engine.splitters``,
         extract_delimiters :1304-1322) -- identical on every rank, the sample being the same;
       * ONE in-place pass cuts the shard into the ranges (delim[p-1], delim[p]]
         (``engine.partition_by_splitters``, the lower-bound range function :188-204);
@@ -407,35 +457,24 @@ def sort_sharded_u32_sampled(engine, keys, recv, dist, world: int, group=None, s
     A single key value heavier than 1/world of the data cannot be split (the reference's limitation too):
     balance degrades, the result stays correct as long as ``recv`` is large enough (else
     :class:`ReceiveOverflow` on every rank)."""
-    import torch
-    if world == 1:
-        engine.sort_u32(keys)
-        return keys
-    n = keys.numel()
-    m = min(sample_per_rank, n)
-    mine = engine.sample_u32(keys, m, seed + 7919 * _rank(dist, group))
-    # ranks may hold different numbers of keys: gather the sample sizes, then the (padded) samples
-    cnt = torch.tensor([m], dtype=torch.int64, device=keys.device)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    sizes = [int(c.item()) for c in cnts]
-    mmax = max(sizes)
-    pad = torch.zeros(max(mmax, 1), dtype=torch.int32, device=keys.device)
-    pad[:m] = mine
-    allp = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(allp, pad, group=group)
-    sample = torch.cat([p[:s] for p, s in zip(allp, sizes)]).contiguous()
-    if sample.numel():
-        engine.sort_u32(sample)
-        delim = engine.splitters_u32(sample, world)                      # int32[world-1], on the device
-    else:
-        delim = torch.zeros(world - 1, dtype=torch.int32, device=keys.device)
-    send = engine.partition_by_splitters(keys, delim, world)            # int64[world]: range sizes, ranges contiguous
-    send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
-    out = recv[:int(sum(got_l))]
-    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
-    engine.sort_u32(out)
-    return out
+    return _sort_sharded_sampled(engine, keys, None, recv, None, dist, world, group, sample_per_rank, seed)
+
+
+def sort_sharded_u64_sampled(engine, keys, recv, dist, world: int, group=None, sample_per_rank: int = 65536,
+                             seed: int = 0x5EED0007):
+    """:func:`sort_sharded_u32_sampled` for u64 keys (int64 tensors holding the bit patterns)."""
+    return _sort_sharded_sampled(engine, keys, None, recv, None, dist, world, group, sample_per_rank, seed)
+
+
+def sort_sharded_pairs_u64_sampled(engine, keys, rids, recv_keys, recv_rids, dist, world: int, group=None,
+                                   sample_per_rank: int = 65536, seed: int = 0x5EED0007):
+    """What the reference actually sorts -- (u64 key, u64 rid) tuples, one (keys, rids) pair of arrays per memory node
+    (src/msb_64.c:2261) -- sharded by the reference's own skew front end (sample :1511-1521, extract_delimiters
+    :1304-1322, range function :188-204) with one range per GPU: the radix split of :func:`sort_sharded_pairs_u64`
+    puts ~75 % of Zipf-distributed keys on one rank, this keeps every rank near n / world.  Keys and rids move
+    together in the one in-place range pass and travel in two all-to-alls with the same splits.  Returns (keys, rids)
+    views of the receive buffers; rank r's keys precede rank r+1's; unstable, like the reference."""
+    return _sort_sharded_sampled(engine, keys, rids, recv_keys, recv_rids, dist, world, group, sample_per_rank, seed)
 
 
 def splitters_equi_depth(sorted_sample, parts: int):

@@ -513,6 +513,12 @@ void orc_sample_u32(const uint32_t *keys, uint64_t n, uint64_t m, uint64_t seed,
 	for (uint64_t p = 0; p < m; ++p) out[p] = keys[orc_mulhi(orc_splitmix64(seed + p), n)];
 }
 
+/* the same for the 64-bit keys the reference itself sorts (its sample is 64-bit, src/msb_64.c:1511-1521) */
+void orc_sample_u64(const uint64_t *keys, uint64_t n, uint64_t m, uint64_t seed, uint64_t *out)
+{
+	for (uint64_t p = 0; p < m; ++p) out[p] = keys[orc_mulhi(orc_splitmix64(seed + p), n)];
+}
+
 /* extract_delimiters (src/msb_64.c:1304-1322) for `parts` ranges (parts - 1 delimiters):
  * delimiter i = sample[(uint64)(percentile * (i+1) - 0.001)], percentile = sample_size / parts; if the run
  * of equal values around the pick extends further behind it than in front of it (and the value is
@@ -547,6 +553,13 @@ uint64_t orc_range_of(const uint64_t *delimiter, uint64_t ndelim, uint64_t key)
 
 /* range sizes of a u32 array under `ndelim` delimiters (counts[0 .. ndelim]) */
 void orc_range_histogram_u32(const uint32_t *keys, uint64_t n, const uint64_t *delimiter, uint64_t ndelim, uint64_t *counts)
+{
+	for (uint64_t p = 0; p <= ndelim; ++p) counts[p] = 0;
+	for (uint64_t i = 0; i < n; ++i) counts[orc_range_of(delimiter, ndelim, keys[i])]++;
+}
+
+/* range sizes of a u64 array (the reference's own key type) under `ndelim` delimiters */
+void orc_range_histogram_u64(const uint64_t *keys, uint64_t n, const uint64_t *delimiter, uint64_t ndelim, uint64_t *counts)
 {
 	for (uint64_t p = 0; p <= ndelim; ++p) counts[p] = 0;
 	for (uint64_t i = 0; i < n; ++i) counts[orc_range_of(delimiter, ndelim, keys[i])]++;

@@ -84,6 +84,8 @@ class _Orc:
         L.orc_range_of.restype = C.c_uint64
         L.orc_range_of.argtypes = [_u64p, C.c_uint64, C.c_uint64]
         L.orc_range_histogram_u32.argtypes = [_u32p, C.c_uint64, _u64p, C.c_uint64, _u64p]
+        L.orc_sample_u64.argtypes = [_u64p, C.c_uint64, C.c_uint64, C.c_uint64, _u64p]
+        L.orc_range_histogram_u64.argtypes = [_u64p, C.c_uint64, _u64p, C.c_uint64, _u64p]
 
 
 _orc = None
@@ -224,6 +226,22 @@ def sample_u32(keys: np.ndarray, m: int, seed: int = 0x5EED0007) -> np.ndarray:
     keys = np.ascontiguousarray(keys, np.uint32)
     out = np.empty(m, np.uint32)
     orc().lib.orc_sample_u32(_ptr(keys, _u32p), keys.size, m, seed, _ptr(out, _u32p))
+    return out
+
+
+def sample_u64(keys: np.ndarray, m: int, seed: int = 0x5EED0007) -> np.ndarray:
+    """The same for 64-bit keys, the reference's own key type."""
+    keys = np.ascontiguousarray(keys, np.uint64)
+    out = np.empty(m, np.uint64)
+    orc().lib.orc_sample_u64(_ptr(keys, _u64p), keys.size, m, seed, _ptr(out, _u64p))
+    return out
+
+
+def range_histogram_u64(keys: np.ndarray, delimiters: np.ndarray) -> np.ndarray:
+    keys = np.ascontiguousarray(keys, np.uint64)
+    d = np.ascontiguousarray(delimiters, np.uint64)
+    out = np.zeros(d.size + 1, np.uint64)
+    orc().lib.orc_range_histogram_u64(_ptr(keys, _u64p), keys.size, _ptr(d, _u64p), d.size, _ptr(out, _u64p))
     return out
 
 

@@ -25,6 +25,23 @@ def test_every_declared_symbol_is_exported():
     assert b"gfx950" in L.msd_version()
 
 
+def test_every_declared_sharded_symbol_is_exported():
+    """include/msd_sharded_hip.h: the multi-GPU entry points live in a library of their own that links the single-GPU
+    library and RCCL; it loads here (no GPU) and exports what the header declares."""
+    from inplacemsdradixsort_amd import _build, _lib
+    R = _lib.load_rccl()
+    declared = _declared("msd_sharded_hip.h")
+    assert {"msd_shard_create", "msd_sort_u32_sharded", "msd_sort_pairs_u64_sharded", "msd_sort_u32_multi"} <= declared
+    missing = [s for s in sorted(declared) if not hasattr(R, s)]
+    assert not missing, missing
+    assert declared == set(_lib.RCCL_EXPORTS), declared ^ set(_lib.RCCL_EXPORTS)
+    import subprocess
+    needed = subprocess.run(["readelf", "-d", _build.RCCL_LIB], capture_output=True, text=True).stdout
+    assert "librccl.so" in needed and "libinpmsdradix_hip.so" in needed
+    # ... and the single-GPU library does not depend on RCCL
+    assert "rccl" not in subprocess.run(["readelf", "-d", _build.LIB], capture_output=True, text=True).stdout
+
+
 def test_mamalloc_is_64_byte_aligned():
     from inplacemsdradixsort_amd import _lib
     L = _lib.load()

@@ -92,20 +92,29 @@ class NumpyEngine:
         a.sort()
 
     # splitter service: the oracle's restatement of the reference's front end (src/msb_64.c:1511-1521, :1304-1322, :188-204)
-    def sample_u32(self, keys, m, seed=0x5EED0007):
+    def sample(self, keys, m, seed=0x5EED0007):
         from oracle import oracle as O
-        return torch.from_numpy(O.sample_u32(keys.numpy().view(np.uint32), m, seed).view(np.int32).copy())
+        if keys.element_size() == 4:
+            return torch.from_numpy(O.sample_u32(keys.numpy().view(np.uint32), m, seed).view(np.int32).copy())
+        return torch.from_numpy(O.sample_u64(keys.numpy().view(np.uint64), m, seed).view(np.int64).copy())
 
-    def splitters_u32(self, sorted_sample, parts):
+    def splitters(self, sorted_sample, parts):
         from oracle import oracle as O
-        d = O.extract_delimiters(sorted_sample.numpy().view(np.uint32).astype(np.uint64), parts)
-        return torch.from_numpy(d.astype(np.uint32).view(np.int32).copy())
+        if sorted_sample.element_size() == 4:
+            d = O.extract_delimiters(sorted_sample.numpy().view(np.uint32).astype(np.uint64), parts)
+            return torch.from_numpy(d.astype(np.uint32).view(np.int32).copy())
+        return torch.from_numpy(O.extract_delimiters(sorted_sample.numpy().view(np.uint64), parts).view(np.int64).copy())
 
-    def partition_by_splitters(self, keys, delims, parts):
+    def partition_by_splitters(self, keys, delims, parts, rids=None):
         from oracle import oracle as O
-        a = keys.numpy().view(np.uint32)
-        r = O.range_of_u32(a, delims.numpy().view(np.uint32))
-        a[:] = a[np.argsort(r, kind="stable")]
+        dt = np.uint32 if keys.element_size() == 4 else np.uint64
+        a = keys.numpy().view(dt)
+        r = O.range_of_u32(a, delims.numpy().view(dt))
+        order = np.argsort(r, kind="stable")
+        a[:] = a[order]
+        if rids is not None:
+            v = rids.numpy()
+            v[:] = v[order]
         return torch.from_numpy(np.bincount(r, minlength=parts).astype(np.int64))
 
 
@@ -336,4 +345,60 @@ def test_sharded_u64_and_tuple_sort_over_gloo(world, pairs):
     for r in range(world):
         assert ((res[r][0] >> np.uint64(64 - lg)) == r).all()
         if pairs:
+            assert (res[r][1] == (res[r][0] ^ np.uint64(0x5A5A5A5A5A5A5A5A))).all()
+
+
+def _zipf64(n, rank):
+    """Zipf-distributed u64 keys: the u32 Zipf ranks spread over 64 bits by squaring (small keys stay heavy)."""
+    from oracle import oracle as O
+    z = O.gen_zipf_u32(n, first=rank * n).astype(np.uint64)
+    return z * z + (z >> np.uint64(3))
+
+
+def _sampled64_worker(rank, world, port, n, pairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from inplacemsdradixsort_amd.dist import sort_sharded_pairs_u64_sampled, sort_sharded_u64_sampled
+    k = _zipf64(n, rank)
+    keys = torch.from_numpy(k.view(np.int64).copy())
+    recv_k = torch.empty(2 * n, dtype=torch.int64)
+    if pairs:
+        rids = torch.from_numpy((k ^ np.uint64(0x5A5A5A5A5A5A5A5A)).view(np.int64).copy())
+        out_k, out_r = sort_sharded_pairs_u64_sampled(NumpyEngine(), keys, rids, recv_k, torch.empty(2 * n, dtype=torch.int64), dist, world)
+        q.put((rank, out_k.numpy().view(np.uint64).copy(), out_r.numpy().view(np.uint64).copy()))
+    else:
+        out = sort_sharded_u64_sampled(NumpyEngine(), keys, recv_k, dist, world)
+        q.put((rank, out.numpy().view(np.uint64).copy(), None))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pairs", [(2, True), (4, False), (4, True), (8, True)])
+def test_sampled_sharded_u64_and_tuple_sort_over_gloo(world, pairs):
+    """The reference's skew front end on its own key type across ranks: Zipf-distributed u64 keys (and tuples), sampled
+    splitters, one range pass, one exchange; global order, every rid with its key, and no rank above 1.6 n where the radix
+    split would put most keys on rank 0."""
+    n = 20000 if world < 8 else 8000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sampled64_worker, args=(r, world, port, n, pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, k, v = q.get(timeout=120)
+        res[r] = (k, v)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    allk = np.concatenate([_zipf64(n, r) for r in range(world)])
+    got = np.concatenate([res[r][0] for r in range(world)])
+    assert (got == np.sort(allk)).all()
+    assert max(res[r][0].size for r in range(world)) < 1.6 * n, [res[r][0].size for r in range(world)]
+    top = world.bit_length() - 1
+    assert (allk >> np.uint64(64 - top) == 0).mean() > 0.7            # (the radix split would send > 70 % to rank 0)
+    if pairs:
+        for r in range(world):
             assert (res[r][1] == (res[r][0] ^ np.uint64(0x5A5A5A5A5A5A5A5A))).all()

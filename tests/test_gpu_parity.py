@@ -402,18 +402,23 @@ def test_reference_api_sort_and_check(ctx):
     import inplacemsdradixsort_amd as M
     n0, n1 = 150000, 90001
     k = O.gen_uniform_u64(n0 + n1, seed=21)
-    keys = [M.mamalloc(n0 * 8).view(np.uint64), M.mamalloc(n1 * 8).view(np.uint64)]
-    rids = [M.mamalloc(n0 * 8).view(np.uint64), M.mamalloc(n1 * 8).view(np.uint64)]
-    keys[0][:], keys[1][:] = k[:n0], k[n0:]
-    rids[0][:], rids[1][:] = k[:n0], k[n0:]
-    size = [n0, n1]
+    # (capacity size * fudge per array, what the reference requires of its caller, src/msb_64.c:1574-1578)
+    keys = [M.mamalloc(2 * n0 * 8).view(np.uint64), M.mamalloc(2 * n1 * 8).view(np.uint64)]
+    rids = [M.mamalloc(2 * n0 * 8).view(np.uint64), M.mamalloc(2 * n1 * 8).view(np.uint64)]
+    keys[0][:n0], keys[1][:n1] = k[:n0], k[n0:]
+    rids[0][:n0], rids[1][:n1] = k[:n0], k[n0:]
+    size = np.array([n0, n1], dtype=np.uint64)        # a numpy array is written back like a list
     desc, times = M.sort(keys, rids, size, threads=64, numa=2, fudge=2.0)
     assert len(desc) == 11 and desc[10] is None and all(d.endswith(": ") or d.rstrip().endswith(":") for d in desc[:10])
-    assert sum(size) == n0 + n1
-    cat = np.concatenate(keys)
-    assert (cat == np.sort(k)).all() and (np.concatenate(rids) == cat).all()
+    assert int(size.sum()) == n0 + n1
+    cat = np.concatenate([keys[a][:int(size[a])] for a in range(2)])
+    assert (cat == np.sort(k)).all() and (np.concatenate([rids[a][:int(size[a])] for a in range(2)]) == cat).all()
     assert M.check(keys, rids, size, numa=2, same=True) == int(k.sum(dtype=np.uint64))
     assert int(times[9]) >= int(times[0])
+    with pytest.raises(M.MsdError):                   # size[] is rewritten: a tuple cannot take the result
+        M.sort(keys, rids, (n0, n1), threads=64, numa=2, fudge=1.0)
+    with pytest.raises(M.MsdError):                   # fudge > 1 needs the room it promises
+        M.sort([keys[0][:n0], keys[1][:n1]], [rids[0][:n0], rids[1][:n1]], [n0, n1], threads=64, numa=2, fudge=2.0)
 
 
 def test_reference_api_rewrites_size_at_key_boundaries():

@@ -116,3 +116,67 @@ def test_partition_by_splitters_full_size_zipf(ctx):
     assert cnt.max() < 0.3 * n, cnt
     del t
     torch.cuda.empty_cache()
+
+
+# ---- the same service on the reference's own key type: 64-bit keys, alone or with their rids
+
+def dev64(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host64(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def make64(kind, n, seed):
+    if kind == "zipf":        # Zipf ranks spread over 64 bits (small keys stay heavy)
+        z = O.gen_zipf_u32(n, seed=seed).astype(np.uint64)
+        return z * z + (z >> np.uint64(3))
+    if kind == "uniform":
+        return O.gen_uniform_u64(n, seed=seed)
+    if kind == "dup5":
+        return (O.gen_uniform_u64(n, seed=seed) % np.uint64(5)) * np.uint64(0x0123456789AB)
+    if kind == "const":
+        return np.full(n, 0xDEADBEEF12345678, np.uint64)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 64), ((1 << 21) + 3, 100000)])
+def test_sample_u64_equals_oracle(ctx, n, m):
+    k = O.gen_uniform_u64(n, seed=5)
+    assert (host64(ctx.sample(dev64(k), m, seed=0xABCDEF)) == O.sample_u64(k, m, seed=0xABCDEF)).all()
+
+
+@pytest.mark.parametrize("kind", ["zipf", "uniform", "dup5", "const"])
+@pytest.mark.parametrize("parts", [2, 8, 64, 256])
+def test_splitters_u64_equal_oracle_and_reference(ctx, kind, parts):
+    k = make64(kind, 300000, seed=21)
+    s = np.sort(O.sample_u64(k, 20000, seed=3))
+    got = host64(ctx.splitters(dev64(s), parts))
+    assert (got == O.extract_delimiters(s, parts)).all()
+    if O.have_ref():
+        assert (got == O.ref_extract_delimiters(s, parts)).all()   # the reference's own function, on its own key type
+
+
+@pytest.mark.parametrize("kind", ["zipf", "uniform", "dup5", "const"])
+@pytest.mark.parametrize("n,parts,pairs", [(5000, 2, False), (70001, 8, True), ((1 << 21) + 77, 8, False), (1 << 21, 64, True), (300000, 3, True)])
+def test_partition_by_splitters_u64_equals_oracle(ctx, kind, n, parts, pairs):
+    k = make64(kind, n, seed=parts + 1)
+    s = np.sort(O.sample_u64(k, min(n, 20000), seed=9))
+    d = O.extract_delimiters(s, parts)
+    t = dev64(k)
+    r = dev64(k ^ np.uint64(0x5A5A5A5A5A5A5A5A)) if pairs else None
+    cnt = ctx.partition_by_splitters(t, dev64(d) if parts > 1 else None, parts, rids=r).cpu().numpy().astype(np.uint64)
+    assert (cnt == O.range_histogram_u64(k, d)).all()
+    out = host64(t)
+    if pairs:
+        assert (host64(r) == (out ^ np.uint64(0x5A5A5A5A5A5A5A5A))).all()   # every rid still with its key
+    rid_in = O.range_of_u32(k, d)
+    exp = k[np.argsort(rid_in, kind="stable")]
+    pos = 0
+    for p in range(parts):
+        c = int(cnt[p])
+        assert (np.sort(out[pos:pos + c]) == np.sort(exp[pos:pos + c])).all(), p
+        pos += c
+    assert pos == n
