@@ -232,6 +232,9 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  *   profiles/r02_sq_counters.json and r02_stamps_classify_direct_before.json keep its measurements).
  * "count16": u32 keys with 16 open bits: 1 (default) = count_place16_kernel for segments of about 2^14
  *   keys, 2 = always, 0 = never (count_place_kernel).
+ * "mid_leaf": u32 keys: 1 (default) = counting-leaf segments the register-resident kernels do not take (17 Ki .. 128 Ki
+ *   keys, crowded ones) are finished by the 16-bit-counter leaf (merge_count_kernel) instead of count_walk_kernel; 0 = never.
+ * "merge_leaf": msd_merge_buckets_u32: 0 (default) = by bucket size, 1 = the register-resident leaf, 2 = the 16-bit-counter leaf.
  * "regpart": u64 keys / tuples: 1 (default) = segments of <= 17408 elements take the register-resident
  *   partition pass (csrc/msd_regpart.hpp) instead of a general round, 0 = never. */
 int msd_set_option(msd_ctx *ctx, const char *name, int64_t value);

@@ -117,6 +117,8 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t next_max;       // per round: largest next parent (saturated to 32 bits)
 	uint32_t rp_children;    // per round: children handed out by regpart_plan_kernel
 	uint32_t nhot;           // per round: lists with sharded claim cursors (chains_kernel)
+	uint32_t nslow2;         // counting-leaf segments merge_count_kernel (list mode) left to count_walk_kernel
+	uint32_t count_ticket4;  // work ticket of merge_count_kernel (list mode)
 	uint32_t pad_;
 };
 static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used for 64-bit atomics");

@@ -55,6 +55,7 @@ struct msd_ctx {
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
+	int mid_leaf = 1;      // u32 keys: merge_count_kernel (list mode) in front of count_walk_kernel (0: A/B comparisons)
 	int merge_leaf = 0;    // msd_merge_buckets_u32: 0 = by bucket size, 1 = merge_place16_kernel, 2 = merge_count_kernel (tests)
 };
 
@@ -1001,9 +1002,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		if (ncount_host && !single_pass) {
 			// persistent workgroups (two per CU fit the LDS), segments handed out by ticket; what the fast
 			// kernel cannot place directly is queued (in the round slab, dead by now) for the walking kernel
-			int rcs = slab_reserve(c, 2 * (size_t)ncount_host * sizeof(Segment) + 4096);
+			int rcs = slab_reserve(c, 3 * (size_t)ncount_host * sizeof(Segment) + 4096);
 			if (rcs) return rcs;
-			Segment *slow = reinterpret_cast<Segment *>(c->slab), *rej16 = slow + ncount_host;
+			Segment *slow = reinterpret_cast<Segment *>(c->slab), *rej16 = slow + ncount_host, *slow2 = rej16 + ncount_host;
 			const uint32_t count_grid = std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count * 2);
 			if constexpr (sizeof(K) == 4) {
 				// u32 keys with 16 open bits (what the planner aims for): the specialised kernel first, the general one
@@ -1021,8 +1022,24 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			} else
 				hipLaunchKernelGGL((count_place_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
 						   keys, small_count, ncount_host, (const uint32_t *)nullptr, slow, ctr);
+			const uint32_t *walk_n = &ctr->nslow;
+			const Segment *walk_list = slow;
+			if constexpr (sizeof(K) == 4) {
+				// What the register-resident kernels left -- segments of 17 Ki .. 128 Ki keys (the mid-size buckets of skewed
+				// inputs), crowded ones -- takes the 16-bit-counter leaf (msd_merge16.hpp, list mode: one workgroup per
+				// segment, all of it counted before the first key is written back, so the sort is in place); only what that
+				// does not take either (a key with >= 2^16 copies, a 256-value group with >= 2^16 keys) walks its counters.
+				if (c->mid_leaf) {
+					hipLaunchKernelGGL((merge_count_kernel<true>), dim3(std::min<uint32_t>(ncount_host, (uint32_t)c->sm_count)), dim3(kMcTh), kMcLds, c->stream,
+							   (const uint32_t *)keys, (uint32_t *)keys, (const uint32_t *)nullptr, (const uint64_t *)nullptr, (const uint64_t *)nullptr,
+							   0u, 0u, 0u, 0u, (const Segment *)slow, (const uint32_t *)&ctr->nslow, slow2, &ctr->nslow2, &ctr->count_ticket4,
+							   (const uint32_t *)nullptr);
+					walk_n = &ctr->nslow2;
+					walk_list = slow2;
+				}
+			}
 			hipLaunchKernelGGL((count_walk_kernel<K>), dim3(count_grid), dim3(kCountTh), kCountLds, c->stream,
-					   keys, slow, &ctr->nslow, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
+					   keys, walk_list, walk_n, small, nsmall_host, (uint32_t)small_max, big, big_cap, ctr);
 			HIPCHK(c, hipGetLastError());
 			phase_mark(c, "count sort");
 			// byte-counter overflows of segments above the LDS-sort capacity joined the big list
@@ -1795,6 +1812,8 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "count16")) {
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
 		c->count16 = (int)value;
+	} else if (!strcmp(name, "mid_leaf")) {
+		c->mid_leaf = value != 0;
 	} else if (!strcmp(name, "merge_leaf")) {
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "merge_leaf must be 0, 1 or 2");
 		c->merge_leaf = (int)value;

@@ -104,21 +104,32 @@ def test_big_counting_sort_paths(ctx, n, kind):
     assert (host(t) == np.sort(k64)).all()
 
 
-def test_counting_leaf_overflow_escalates_to_multi_workgroup_sort(ctx):
-    """A medium segment (above the LDS-sort capacity) whose hot value overflows the 8-bit LDS
-    counters must be finished by the multi-workgroup counting sort."""
+@pytest.mark.parametrize("mid_leaf,hot_share", [(1, 0.3), (0, 0.3), (1, 0.9)])
+def test_counting_leaf_overflow_escalates(ctx, mid_leaf, hot_share):
+    """A medium segment (above the LDS-sort capacity, ~100 K keys) whose hot value overflows the 8-bit LDS counters of
+    the register-resident leaves: the 16-bit-counter leaf (merge_count_kernel, list mode) finishes it -- unless it is
+    switched off or the hot value has more copies than a 16-bit counter holds (hot_share 0.9: ~90 K copies); then the
+    segment escalates to the multi-workgroup counting sort."""
     rng = np.random.default_rng(42)
     n = 1 << 22
     k = rng.integers(0, 1 << 21, n, dtype=np.uint32)
-    hot = rng.random(n) < 0.02                       # one child of the first round gets ~100 K keys ...
+    hot = rng.random(n) < 0.025                      # one child of the first round gets ~100 K keys ...
     k[hot] = (np.uint32(0x55) << np.uint32(13)) | rng.integers(0, 1 << 13, int(hot.sum()), dtype=np.uint32)
-    hotter = hot & (rng.random(n) < 0.3)             # ... a quarter of them one single value
+    hotter = hot & (rng.random(n) < hot_share)       # ... a good part of them one single value
     k[hotter] = (np.uint32(0x55) << np.uint32(13)) | np.uint32(77)
     t = dev(k)
-    ctx.sort_u32(t)
+    ctx.set_option("mid_leaf", mid_leaf)
+    try:
+        ctx.sort_u32(t)
+    finally:
+        ctx.set_option("mid_leaf", 1)
     st = ctx.stats()
     assert (host(t) == np.sort(k)).all()
-    assert st.get("big_count_segments", 0) >= 1 and st.get("count_segments", 0) >= 1, st
+    assert st.get("count_segments", 0) >= 1, st
+    if mid_leaf == 0 or hot_share > 0.8:
+        assert st.get("big_count_segments", 0) >= 1, st
+    else:
+        assert st.get("big_count_segments", 0) == 0, st
 
 
 def test_sort_u32_config_c1(ctx):
