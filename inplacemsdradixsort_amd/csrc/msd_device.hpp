@@ -833,6 +833,7 @@ __device__ __forceinline__ bool wave_select_smallest(uint32_t v, bool elig, int 
 
 } // namespace msd
 #include "msd_direct.hpp"
+#include "msd_stream2.hpp"
 namespace msd {
 
 // ------------------------------------------------- child geometry per parent

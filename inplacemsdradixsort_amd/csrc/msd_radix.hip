@@ -55,6 +55,7 @@ struct msd_ctx {
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
+	int stream_kernel = 2; // streaming classify: 2 = classify_stream2_kernel (lean tile loop), 1 = classify_kernel (round 2; A/B comparisons)
 	int mid_leaf = 1;      // u32 keys: merge_count_kernel (list mode) in front of count_walk_kernel (0: A/B comparisons)
 	int merge_leaf = 0;    // msd_merge_buckets_u32: 0 = by bucket size, 1 = merge_place16_kernel, 2 = merge_count_kernel (tests)
 };
@@ -842,21 +843,28 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			phase_mark(c, "A classify direct");
 		}
 		if (!tried_direct || c->direct_mode != 2) {
-			constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
 			const uint32_t *run_if = tried_direct ? (const uint32_t *)&ctr->direct_uneven : (const uint32_t *)nullptr;
-			bool launched = false;
-			if constexpr (kHasRange<K, V>) {
-				if (splitters) {
+			if (c->stream_kernel == 2) { // the lean tile loop (msd_stream2.hpp)
+				constexpr size_t s2_lds = Stream2Lds<K, V>::bytes;
+				if (splitters)
+					hipLaunchKernelGGL((classify_stream2_kernel<K, V, true>), dim3(ns), dim3(Stream2Cfg<K, V>::TH), s2_lds + kP * sizeof(K), c->stream,
+							   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, splitters, run_if);
+				else
+					hipLaunchKernelGGL((classify_stream2_kernel<K, V, false>), dim3(ns), dim3(Stream2Cfg<K, V>::TH), s2_lds, c->stream,
+							   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, (const K *)nullptr, run_if);
+			} else { // round 2's kernel (A/B comparisons)
+				constexpr size_t classify_lds = ClassifyLds<K, V>::bytes;
+				if (splitters)
 					hipLaunchKernelGGL((classify_kernel<K, V, true>), dim3(ns), dim3(C::TH), classify_lds + kP * sizeof(K), c->stream,
 							   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
 							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, splitters, run_if);
-					launched = true;
-				}
+				else
+					hipLaunchKernelGGL((classify_kernel<K, V, false>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
+							   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
+							   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, (const K *)nullptr, run_if);
 			}
-			if (!launched)
-				hipLaunchKernelGGL((classify_kernel<K, V, false>), dim3(ns), dim3(C::TH), classify_lds, c->stream,
-						   keys, vals, rb.stripes, rb.parents, block_map, rb.fb, rb.lo_cnt, rb.lo_off,
-						   (K *)rb.lo_keys, rb.lo_vals, rb.nfull, (const K *)nullptr, run_if);
 			HIPCHK(c, hipGetLastError());
 		}
 		const uint8_t *full_map = tried_direct ? (const uint8_t *)slot_full : (const uint8_t *)nullptr;
@@ -1160,6 +1168,10 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 	if constexpr (kHasRange<K, V>)
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_kernel<K, V, true>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ClassifyLds<K, V>::bytes + kP * sizeof(K))));
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_stream2_kernel<K, V, false>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Stream2Lds<K, V>::bytes));
+	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_stream2_kernel<K, V, true>),
+				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(Stream2Lds<K, V>::bytes + kP * sizeof(K))));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&lds_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct2_kernel<K, V>),
@@ -1812,6 +1824,9 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "count16")) {
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
 		c->count16 = (int)value;
+	} else if (!strcmp(name, "stream_kernel")) {
+		if (value < 1 || value > 2) return fail(c, MSD_EINVAL, "stream_kernel must be 1 or 2");
+		c->stream_kernel = (int)value;
 	} else if (!strcmp(name, "mid_leaf")) {
 		c->mid_leaf = value != 0;
 	} else if (!strcmp(name, "merge_leaf")) {

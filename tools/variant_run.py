@@ -76,7 +76,7 @@ if hasattr(L, "msd_debug_stamps"):
     if name.startswith("cstamps"):  # count_place_kernel sections
         NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
     if name.startswith("sstamps"):  # classify_kernel (streaming) sections
-        NAMES = ["ranks", "B1", "bookkeeping", "B2", "scatter", "B3", "drain", "refill issue", "flush", "loop", "-", "tiles"]
+        NAMES = ["places", "B1", "bucket round", "B2", "waiting keys' places + flush", "B3", "waiting keys", "refill issue", "-", "loop", "-", "tiles"]  # classify_stream2_kernel
     if name.startswith("chstamps"):  # chains_kernel sections (per wave step); 10: blocks moved per step
         NAMES = ["chain starts", "owner flags+grouping", "claim", "list geometry+entry", "block loads+stores", "-", "-", "-", "-", "-", "blocks moved", "steps"]
     if name.startswith("wstamps"):  # bigcount_write_kernel sections
