@@ -232,6 +232,8 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  *   profiles/r02_sq_counters.json and r02_stamps_classify_direct_before.json keep its measurements).
  * "count16": u32 keys with 16 open bits: 1 (default) = count_place16_kernel for segments of about 2^14
  *   keys, 2 = always, 0 = never (count_place_kernel).
+ * "leaf17": tuples: 1 (default) = segments of <= 17408 tuples are finished in one pass by leaf17_kernel (read once,
+ *   sorted in registers and LDS, written once), 0 = register partition + the small leaves (round 2).
  * "stream_kernel": the streaming classify of rounds that do not place directly: 2 (default) = classify_stream2_kernel
  *   (one fetch-add per key, no per-key second pass), 1 = round 2's classify_kernel.
  * "mid_leaf": u32 keys: 1 (default) = counting-leaf segments the register-resident kernels do not take (17 Ki .. 128 Ki

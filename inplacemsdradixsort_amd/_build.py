@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libinpmsdradix_hip.so")
 # diagnostic build with in-kernel cycle stamps (tools/variant_run.py); never what tests or bench.py load
 STAMPS_LIB = os.path.join(HERE, "libinpmsdradix_hip_stamps.so")
 SOURCES = ["msd_radix.hip", "msb_64_shim.hip"]
-DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_stream2.hpp", "msd_count16.hpp", "msd_merge16.hpp", "msd_regpart.hpp", "msd_bigcount.hpp",
+DEPS = SOURCES + ["msd_device.hpp", "msd_direct.hpp", "msd_stream2.hpp", "msd_count16.hpp", "msd_merge16.hpp", "msd_leaf17.hpp", "msd_regpart.hpp", "msd_bigcount.hpp",
                   os.path.join("..", "..", "include", "msd_radix_hip.h"), os.path.join("..", "..", "include", "msb_64.h")]
 # the multi-GPU entry points (include/msd_sharded_hip.h): a library of its own, linked against the one above and RCCL
 RCCL_LIB = os.path.join(HERE, "libinpmsdradix_hip_rccl.so")

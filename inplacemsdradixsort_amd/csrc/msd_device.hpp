@@ -2192,6 +2192,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 }
 
 } // namespace msd
+#include "msd_leaf17.hpp"
 #include "msd_bigcount.hpp"
 namespace msd {
 

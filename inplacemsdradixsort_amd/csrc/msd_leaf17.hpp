@@ -1,0 +1,285 @@
+// msd_leaf17.hpp -- the leaf for (u64 key, u64 rid) segments of up to 17408 tuples: the whole segment is sorted in the
+// registers and the LDS of ONE 1024-thread workgroup, read once and written once (included by msd_device.hpp).
+//
+// Round 2 finished such a segment (2^30 tuples: 65536 of them after two 8-bit rounds, 48 open bits) in two passes:
+// regpart_kernel split it by 2-3 bits (read + write of every tuple), leaf_count_sort_kernel sorted the <= 3072-tuple
+// children (read + write again): 139 B per tuple for the whole sort, four full passes.  This kernel
+// is regpart_kernel's data movement -- 16-byte loads on the arrays' grid into registers, keys and then payloads through
+// one LDS staging buffer to their places and out as whole vectors -- around leaf_count_sort_kernel's ranking: ONE
+// unstable counting pass over the top 13 of the bits that vary in the segment (16-bit LDS counters, the fetch-add's
+// return value is the rank among equal values, an in-place scan gives positions), the keys go to those positions in LDS,
+// and every element then finds its own place inside its group of equal counted bits from its three neighbours on either
+// side (one LDS round trip; longer groups continue element by element; a group longer than 48 rejects the segment,
+// untouched, to regpart + the small leaves).  Payloads never pass through LDS before their final permutation: they wait
+// in registers.  This is the reference's in-cache finish of a bucket (local_radixsort down to insertion sort,
+// src/msb_64.c:1007-1035, :126-149) with the register file and LDS as the cache.
+#pragma once
+
+namespace msd {
+
+constexpr int kL17Th = 1024;
+constexpr int kL17Vec = 8;                                           // 16-byte vectors (2 elements) per thread and array
+constexpr uint32_t kL17Cap = kL17Th * (kL17Vec * 2 + 1);              // 17408 elements on the 16-byte grid
+constexpr int kL17Bits = 13;                                         // counted bits
+constexpr size_t kL17Side = kL17Cap > (((size_t)1 << kL17Bits) * 2) ? kL17Cap : (((size_t)1 << kL17Bits) * 2); // counters, later a byte per position
+constexpr size_t kL17Lds = (size_t)kL17Cap * 8 + kL17Side + 64 * 8 + 256; // staging | counters / distances | junk | misc
+static_assert(kL17Lds <= 160 * 1024, "one workgroup per CU");
+constexpr uint32_t kL17MaxGroup = 48;
+
+template <typename V>
+__global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict__ keys, uint64_t *__restrict__ vals,
+	const Segment *__restrict__ segs, uint32_t nsegs, Segment *__restrict__ rejected, uint32_t *__restrict__ nrejected,
+	Counters *__restrict__ ctr)
+{
+	constexpr bool HV = has_val<V>::value;
+	constexpr int TH = kL17Th, NV = kL17Vec, NK = NV * 2 + 1, LB = kL17Bits;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint64_t *stage = reinterpret_cast<uint64_t *>(smem);                        // kL17Cap elements
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem + (size_t)kL17Cap * 8);     // 2 x 16-bit counters per word
+	uint64_t *junk = reinterpret_cast<uint64_t *>(smem + (size_t)kL17Cap * 8 + kL17Side); // per-lane junk word
+	uint32_t *wtot = reinterpret_cast<uint32_t *>(junk + 64);                    // 16 wave totals, [16] flag
+	uint64_t *s_or = reinterpret_cast<uint64_t *>(wtot + 32);                    // OR / AND of the keys
+	const uint32_t tid0 = threadIdx.x;
+	auto rfl = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+
+	// (Prefetching the next segment's keys behind the keys' write-back was tried: carried across the loop through its three
+	// early ways out the key registers become conditionally written loop-carried values -- 266 spilled registers.)
+	MSD_STAMP_DECL(9);
+	MSD_STAMP_START();
+	for (uint32_t si = blockIdx.x; si < nsegs; si += gridDim.x) {
+		MSD_STAMP(9);
+		MSD_STAMP_TICK(11);
+		// (the thread index is made opaque per segment: addresses and predicates derived from it would otherwise be hoisted
+		// out of this loop, kept in registers for its whole life and spilled)
+		uint32_t tid = tid0;
+		asm volatile("" : "+v"(tid));
+		const uint32_t lane = tid & 63u, w = tid >> 6;
+		const Segment g = segs[si];
+		const uint64_t start = (uint64_t)rfl((uint32_t)g.start) | ((uint64_t)rfl((uint32_t)(g.start >> 32)) << 32);
+		const uint64_t cnt64 = (uint64_t)rfl((uint32_t)g.count) | ((uint64_t)rfl((uint32_t)(g.count >> 32)) << 32);
+		const uint32_t bits = rfl(g.bits);
+		const uint32_t off = (uint32_t)(start & 1u);
+		if (cnt64 + off > kL17Cap || cnt64 < 2 || bits == 0 || bits > 64) { // (the host only sends segments that fit)
+			if (cnt64 + off > kL17Cap && tid == 0) atomicAdd(&ctr->errors, 1u);
+			continue;
+		}
+		const uint32_t n = (uint32_t)cnt64, tot = n + off; // the segment on the 16-byte grid: elements [off, tot)
+		uint64_t *kb = keys + (start - off), *vb = HV ? vals + (start - off) : nullptr;
+		// ---- read: vector v of thread t = grid elements (v * TH + t) * 2, + 1; tail element NV * TH * 2 + t
+		uint64_t k[NK];
+		const uint32_t lastv = (tot - 1u) >> 1;
+#pragma unroll
+		for (int v = 0; v < NV; ++v) {
+			const uint32_t q = min((uint32_t)(v * TH) + tid, lastv) * 2u; // (beyond the segment: its last vector again, ignored)
+			const u32x4 a = *reinterpret_cast<const u32x4 *>(kb + q);
+			k[2 * v] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+			k[2 * v + 1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+		}
+		k[NK - 1] = kb[min((uint32_t)(NV * TH * 2) + tid, tot - 1u)];
+		auto elem = [&](int u) -> uint32_t { return u < NV * 2 ? (uint32_t)((u / 2) * TH * 2) + tid * 2 + (u % 2) : (uint32_t)(NV * TH * 2) + tid; };
+		// ---- which bits vary (OR / AND over the segment), counters cleared
+		for (uint32_t j = tid; j < ((uint32_t)1 << LB) / 2; j += TH) cw[j] = 0;
+		if (tid == 0) {
+			s_or[0] = 0;
+			s_or[1] = ~0ull;
+			wtot[16] = 0;
+		}
+		uint64_t k_or = 0, k_and = ~0ull;
+#pragma unroll
+		for (int u = 0; u < NK; ++u) {
+			const uint32_t el = elem(u);
+			if (el >= off && el < tot) {
+				k_or |= k[u];
+				k_and &= k[u];
+			}
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			k_or |= __shfl_xor(k_or, o);
+			k_and &= __shfl_xor(k_and, o);
+		}
+		__syncthreads();
+		if (lane == 0) {
+			atomicOr(reinterpret_cast<unsigned long long *>(&s_or[0]), (unsigned long long)k_or);
+			atomicAnd(reinterpret_cast<unsigned long long *>(&s_or[1]), (unsigned long long)k_and);
+		}
+		__syncthreads();
+		MSD_STAMP(0); // keys arrive, OR / AND, clear, two barriers
+		const uint64_t openmask = bits >= 64 ? ~0ull : ((1ull << bits) - 1ull);
+		const uint64_t vopen = (s_or[0] ^ s_or[1]) & openmask;
+		if (vopen == 0) { // (uniform) constant on the open bits: already sorted
+			__syncthreads();
+			continue;
+		}
+		const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
+		const uint32_t shift = nbits > (uint32_t)LB ? nbits - LB : 0;
+		const uint32_t mask = (1u << (nbits - shift)) - 1u;
+		// ---- rank among the elements with equal counted bits: one LDS fetch-add per element
+		uint32_t pr[NK]; // rank, then position; bit 31: not an element of the segment
+#pragma unroll
+		for (int u = 0; u < NK; ++u) {
+			const uint32_t el = elem(u);
+			const bool in = el >= off && el < tot;
+			const uint32_t v = (uint32_t)(k[u] >> shift) & mask, sh = 16u * (v & 1u);
+			uint32_t *a = in ? cw + (v >> 1) : reinterpret_cast<uint32_t *>(junk + lane);
+			pr[u] = ((atomicAdd(a, 1u << sh) >> sh) & 0xFFFFu) | (in ? 0u : 0x80000000u);
+			if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0); // (six fetch-adds in flight: all seventeen with their addresses spill)
+		}
+		MSD_STAMP(1); // fetch-adds
+		__syncthreads();
+		// ---- counts -> exclusive positions, in place; thread t owns 4 words
+		{
+			constexpr uint32_t WPT = (((uint32_t)1 << LB) / 2) / TH;
+			static_assert(WPT >= 1, "counter words per thread");
+			const uint32_t w0 = tid * WPT;
+			uint32_t x[WPT], tsum = 0;
+#pragma unroll
+			for (uint32_t j = 0; j < WPT; ++j) {
+				x[j] = cw[w0 + j];
+				tsum += (x[j] & 0xFFFFu) + (x[j] >> 16);
+			}
+			const uint32_t inc = wave_incl_scan(tsum);
+			if (lane == 63) wtot[w] = inc;
+			__syncthreads();
+			uint32_t run = inc - tsum;
+			for (uint32_t ww = 0; ww < w; ++ww) run += wtot[ww];
+#pragma unroll
+			for (uint32_t j = 0; j < WPT; ++j) {
+				const uint32_t lo = x[j] & 0xFFFFu, hi = x[j] >> 16;
+				cw[w0 + j] = run | ((run + lo) << 16);
+				run += lo + hi;
+			}
+		}
+		__syncthreads();
+		MSD_STAMP(2); // scan (three barriers)
+		// ---- the keys to their positions (groups of equal counted bits are contiguous now)
+#pragma unroll
+		for (int u = 0; u < NK; ++u) {
+			const uint32_t v = (uint32_t)(k[u] >> shift) & mask;
+			const uint32_t p = ((cw[v >> 1] >> (16u * (v & 1u))) & 0xFFFFu) + (pr[u] & 0xFFFFu);
+			uint64_t *o = (pr[u] >> 31) ? junk + lane : stage + p;
+			*o = k[u];
+			pr[u] = (pr[u] & 0x80000000u) | p;
+			if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+		}
+		__syncthreads();
+		MSD_STAMP(3); // keys into LDS
+		const uint64_t lowmask = shift ? (1ull << shift) - 1ull : 0ull;
+		const bool groups = shift && (vopen & lowmask) != 0; // more bits vary than were counted
+		bool bad = false;
+		if (groups) { // (uniform)
+			// two elements kL17MaxGroup apart share a group only if the group is longer than that
+			bool too_long = false;
+			for (uint32_t i = tid; i + kL17MaxGroup < n; i += TH)
+				if ((stage[i] >> shift) == (stage[i + kL17MaxGroup] >> shift)) too_long = true;
+			if (too_long) wtot[16] = 1;
+			__syncthreads();
+			bad = wtot[16] != 0;
+			if (bad) { // (nothing has been written back: the segment goes to the register partition + the small leaves)
+				if (tid == 0) rejected[atomicAdd(nrejected, 1u)] = g;
+				__syncthreads();
+				continue;
+			}
+			// every position finds its element's place inside its group: first slot of the group + the members with a smaller
+			// key (or an equal key further left); LDS is only read.  The loop runs over POSITIONS (not unrolled: done for a
+			// thread's own 17 elements in registers, the look-ups of all of them are in flight at once and a hundred registers
+			// spill) and leaves the distance to the final place -- within +-48 -- as a byte where the counters were; the
+			// elements' owners pick it up behind the barrier.
+			MSD_STAMP(4); // long-group check
+			int8_t *dl = reinterpret_cast<int8_t *>(cw);
+			constexpr uint32_t WIN = 3;
+#pragma unroll 1
+			for (uint32_t idx = tid; idx < n; idx += TH) {
+				const uint64_t me = stage[idx], hi = me >> shift;
+				uint64_t lk[WIN], rk[WIN];
+#pragma unroll
+				for (uint32_t d = 0; d < WIN; ++d) {
+					lk[d] = stage[idx > d ? idx - d - 1 : 0u];
+					rk[d] = stage[min(idx + d + 1, n - 1u)];
+				}
+				uint32_t left = 0, before = 0, right = 0;
+				bool ml = true, mr = true;
+#pragma unroll
+				for (uint32_t d = 0; d < WIN; ++d) {
+					ml = ml && idx > d && (lk[d] >> shift) == hi;          // members to the left: those <= me come first
+					before += ml && lk[d] <= me ? 1u : 0u;
+					left += ml ? 1u : 0u;
+					mr = mr && idx + d + 1 < n && (rk[d] >> shift) == hi;  // members to the right: those < me come first
+					before += mr && rk[d] < me ? 1u : 0u;
+					right += mr ? 1u : 0u;
+				}
+				if (ml) { // the group goes on beyond the window
+					while (idx > left) {
+						const uint64_t o = stage[idx - left - 1];
+						if ((o >> shift) != hi) break;
+						before += o <= me ? 1u : 0u;
+						++left;
+					}
+				}
+				if (mr) {
+					for (uint32_t e = idx + right + 1; e < n; ++e) {
+						const uint64_t o = stage[e];
+						if ((o >> shift) != hi) break;
+						before += o < me ? 1u : 0u;
+					}
+				}
+				dl[idx] = (int8_t)((int)before - (int)left);
+			}
+			__syncthreads();
+#pragma unroll
+			for (int u = 0; u < NK; ++u) {
+				const uint32_t idx = (pr[u] >> 31) ? 0u : (pr[u] & 0x7FFFFFFFu);
+				pr[u] = (pr[u] & 0x80000000u) | (uint32_t)((int)idx + (int)dl[idx]);
+			}
+			__syncthreads(); // every look-up is done: the staging buffer is free
+		}
+		// ---- keys, then payloads: to their final places in the staging buffer (on the array's 16-byte grid), out as whole vectors
+		auto permute = [&](const uint64_t(&x)[NK], uint64_t *gb, bool stage_holds_it) {
+			if (!stage_holds_it) {
+#pragma unroll
+				for (int u = 0; u < NK; ++u) {
+					uint64_t *o = (pr[u] >> 31) ? junk + lane : stage + (pr[u] & 0x7FFFFFFFu) + off;
+					*o = x[u];
+				}
+				__syncthreads();
+			}
+			const uint32_t v_first = off, v_end = tot >> 1; // whole vectors: [v_first, v_end)
+#pragma unroll
+			for (int v = 0; v < NV; ++v) {
+				const uint32_t q = (uint32_t)(v * TH) + tid;
+				if (q >= v_first && q < v_end) reinterpret_cast<u32x4 *>(gb)[q] = reinterpret_cast<const u32x4 *>(stage)[q];
+			}
+			{
+				const uint32_t q = (uint32_t)(NV * TH) + tid; // (at most kL17Cap / 2 - NV * TH = 512 more vectors)
+				if (q < v_end) reinterpret_cast<u32x4 *>(gb)[q] = reinterpret_cast<const u32x4 *>(stage)[q];
+			}
+			if (tid == 0) { // the single elements at both ends
+				if (off && tot > 1) gb[1] = stage[1];
+				if ((tot & 1u) && tot - 1u >= off && (tot - 1u != 1u || !off)) gb[tot - 1u] = stage[tot - 1u];
+			}
+			__syncthreads();
+		};
+		MSD_STAMP(5); // fix-up
+		// the payloads start travelling while the keys are permuted and stored (loaded before the fix-up -- 34 more registers
+		// held through it -- the kernel spills more and runs 7 % slower: 12.8 against 11.9 ms at 2^30 tuples)
+		uint64_t r[HV ? NK : 1];
+		if constexpr (HV) {
+#pragma unroll
+			for (int v = 0; v < NV; ++v) {
+				const uint32_t q = min((uint32_t)(v * TH) + tid, lastv) * 2u;
+				const u32x4 b = *reinterpret_cast<const u32x4 *>(vb + q);
+				r[2 * v] = (uint64_t)b.x | ((uint64_t)b.y << 32);
+				r[2 * v + 1] = (uint64_t)b.z | ((uint64_t)b.w << 32);
+			}
+			r[NK - 1] = vb[min((uint32_t)(NV * TH * 2) + tid, tot - 1u)];
+		}
+		// (without groups and with off == 0 the keys already lie at their final places in the staging buffer)
+		permute(k, kb, !groups && off == 0);
+		MSD_STAMP(6); // keys out
+		if constexpr (HV) permute(r, vb, false);
+		MSD_STAMP(7); // payloads out
+	}
+	MSD_STAMP_FLUSH(TH / 64);
+}
+
+} // namespace msd

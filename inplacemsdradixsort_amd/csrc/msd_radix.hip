@@ -55,6 +55,7 @@ struct msd_ctx {
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
+	int leaf17 = 1;        // tuples: segments of <= 17408 tuples are finished by leaf17_kernel (0: register partition + small leaves; A/B comparisons)
 	int stream_kernel = 2; // streaming classify: 2 = classify_stream2_kernel (lean tile loop), 1 = classify_kernel (round 2; A/B comparisons)
 	int mid_leaf = 1;      // u32 keys: merge_count_kernel (list mode) in front of count_walk_kernel (0: A/B comparisons)
 	int merge_leaf = 0;    // msd_merge_buckets_u32: 0 = by bucket size, 1 = merge_place16_kernel, 2 = merge_count_kernel (tests)
@@ -640,6 +641,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		HIPCHK(c, hipMemsetAsync(ctr, 0, sizeof(Counters), c->stream));
 		return MSD_OK;
 	};
+	bool leaf17_ok = true; // (tuples) leaf17_kernel has rejected nothing yet in this call
+	uint32_t dev_bits_min = 0; // fewest open bits among the segments of dev_list
 	bool again = true;
 	while (again) {
 	again = false;
@@ -653,6 +656,57 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 				std::vector<Segment> fit, rest;
 				if (!dev_np)
 					for (auto &sg : cur) (sg.count + 1 <= kRpCap && sg.count > small_max ? fit : rest).push_back(sg);
+				if constexpr (HV) {
+					// ---- tuples: such a segment is FINISHED in one pass by leaf17_kernel (msd_leaf17.hpp: read once, sorted in
+					// registers and LDS, written once) instead of a register partition + the small leaves; what it rejects
+					// (a group of > 48 tuples equal on the counted bits) takes that way.  A leaf must not run behind an
+					// unconfirmed leading-bit skip.
+					// (segments with <= 16 open bits -- tuples whose upper key half is constant, config 5b -- stay with the register
+					// partition: its children have <= 13 open bits, which the small leaf counts in one go without any fix-up)
+					bool wide = dev_np ? dev_bits_min > 16u : !fit.empty();
+					for (auto &sg : fit) wide = wide && sg.bits > 16u;
+					if (c->leaf17 && leaf17_ok && !unverified && wide && (dev_np || fit.size() >= 64 || (!fit.empty() && rest.empty()))) {
+						const bool on_device = dev_np != 0;
+						const uint32_t np = on_device ? dev_np : (uint32_t)fit.size();
+						dev_np = 0;
+						int rc = slab_reserve(c, 2 * (size_t)np * sizeof(Segment) + 4096);
+						if (!rc) rc = pinned_reserve(c, (size_t)np * sizeof(Segment) + 4096);
+						if (rc) return rc;
+						Segment *d_segs = reinterpret_cast<Segment *>(c->slab), *d_rej = d_segs + np;
+						if (on_device)
+							HIPCHK(c, hipMemcpyAsync(d_segs, dev_list, (size_t)np * sizeof(Segment), hipMemcpyDeviceToDevice, c->stream));
+						else {
+							HIPCHK(c, hipStreamSynchronize(c->stream)); // the staging buffer may still be in flight
+							memcpy(c->pinned, fit.data(), (size_t)np * sizeof(Segment));
+							HIPCHK(c, hipMemcpyAsync(d_segs, c->pinned, (size_t)np * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
+						}
+						HIPCHK(c, hipMemsetAsync(&ctr->nslow2, 0, sizeof(uint32_t), c->stream));
+						phase_mark(c, "plan+upload");
+						hipLaunchKernelGGL((leaf17_kernel<V>), dim3(std::min<uint32_t>(np, (uint32_t)c->sm_count)), dim3(kL17Th), kL17Lds, c->stream,
+								   (uint64_t *)keys, vals, (const Segment *)d_segs, np, d_rej, &ctr->nslow2, ctr);
+						HIPCHK(c, hipGetLastError());
+						phase_mark(c, "leaf17");
+						Counters hc;
+						HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+						HIPCHK(c, hipStreamSynchronize(c->stream));
+						memcpy(&hc, c->pinned, sizeof hc);
+						if (hc.errors) return fail(c, MSD_EINTERNAL, "leaf17: %u internal invariant violations", hc.errors);
+						add_stat(c, "leaf17_segments", np - hc.nslow2);
+						cur = rest;
+						if (hc.nslow2) { // rejected segments: the register partition + the small leaves finish them
+							rc = pinned_reserve(c, (size_t)hc.nslow2 * sizeof(Segment));
+							if (rc) return rc;
+							HIPCHK(c, hipMemcpyAsync(c->pinned, d_rej, (size_t)hc.nslow2 * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
+							HIPCHK(c, hipStreamSynchronize(c->stream));
+							cur.insert(cur.end(), (Segment *)c->pinned, (Segment *)c->pinned + hc.nslow2);
+							std::sort(cur.begin(), cur.end(), [](const Segment &a, const Segment &b) { return a.start < b.start; });
+							leaf17_ok = false; // (for the rest of this call)
+							add_stat(c, "leaf17_rejected", hc.nslow2);
+						}
+						phase_mark(c, "readback");
+						continue;
+					}
+				}
 				if (dev_np || fit.size() >= 64 || (!fit.empty() && rest.empty())) {
 					const bool on_device = dev_np != 0;
 					std::vector<Parent> ps(fit.size());
@@ -972,6 +1026,8 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			if (c->regpart && hc.next_parents >= 64 && (uint64_t)hc.next_max + 1 <= kRpCap) {
 				HIPCHK(c, hipMemcpyAsync(dev_list, rb.next_parents, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToDevice, c->stream));
 				dev_np = hc.next_parents;
+				dev_bits_min = 64;
+				for (size_t i = 0; i < np; ++i) dev_bits_min = std::min(dev_bits_min, rp.parents[i].shift);
 				stays_on_device = true;
 			}
 		}
@@ -1176,9 +1232,13 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)SortLds<K, V>::bytes));
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&classify_direct2_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)Direct2Lds<K, V>::bytes));
-	if constexpr (sizeof(K) == 8)
+	if constexpr (sizeof(K) == 8) {
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&regpart_kernel<V>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRpLds));
+		if constexpr (has_val<V>::value)
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf17_kernel<V>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL17Lds));
+	}
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));
 	if constexpr (!has_val<V>::value) {
@@ -1824,6 +1884,8 @@ int msd_set_option(msd_ctx *c, const char *name, int64_t value)
 	} else if (!strcmp(name, "count16")) {
 		if (value < 0 || value > 2) return fail(c, MSD_EINVAL, "count16 must be 0, 1 or 2");
 		c->count16 = (int)value;
+	} else if (!strcmp(name, "leaf17")) {
+		c->leaf17 = value != 0;
 	} else if (!strcmp(name, "stream_kernel")) {
 		if (value < 1 || value > 2) return fail(c, MSD_EINVAL, "stream_kernel must be 1 or 2");
 		c->stream_kernel = (int)value;

@@ -51,25 +51,56 @@ def test_count16_modes(ctx, count16, n, kind):
     assert (host(t2[4:n - 3]) == np.sort(k[4:n - 3])).all() and (host(t2[:4]) == k[:4]).all() and (host(t2[n - 3:]) == k[n - 3:]).all()
 
 
-@pytest.mark.parametrize("regpart", [0, 1])
-@pytest.mark.parametrize("n,shr", [(300_001, 0), ((1 << 21) + 7, 0), (1 << 22, 40), (4_000_000, 0)])
-def test_regpart_modes_pairs(ctx, regpart, n, shr):
-    """(key, rid) tuples whose last partition round has parents of a few thousand tuples: with and without the
-    register-resident pass the key sequence is the oracle's and the rids follow their keys."""
+@pytest.mark.parametrize("regpart,leaf17", [(0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("n,shr", [(300_001, 0), ((1 << 21) + 7, 0), (1 << 22, 40), (4_000_000, 0), (4_000_000, 30)])
+def test_regpart_modes_pairs(ctx, regpart, leaf17, n, shr):
+    """(key, rid) tuples whose last partition round has parents of a few thousand tuples: with the general round, with
+    the register-resident pass + small leaves, and with the one-pass leaf for segments of <= 17408 tuples (leaf17_kernel)
+    the key sequence is the oracle's and the rids follow their keys."""
     import torch
     k = O.gen_uniform_u64(n, seed=51) >> np.uint64(shr)
     ctx.set_option("regpart", regpart)
-    tk = dev(k)
-    tr = torch.arange(n, dtype=torch.int64, device="cuda")
-    ctx.sort_pairs_u64(tk, tr)
+    ctx.set_option("leaf17", leaf17)
+    try:
+        tk = dev(k)
+        tr = torch.arange(n, dtype=torch.int64, device="cuda")
+        ctx.sort_pairs_u64(tk, tr)
+    finally:
+        ctx.set_option("regpart", 1)
+        ctx.set_option("leaf17", 1)
     out, rid = host(tk), tr.cpu().numpy()
     assert (out == np.sort(k)).all()
     assert (k[rid] == out).all() and (np.sort(rid) == np.arange(n)).all()
     st = ctx.stats()
     if regpart == 0:
-        assert st.get("regpart_rounds", 0) == 0
-    elif n == 4_000_000:
-        assert st.get("regpart_rounds", 0) >= 1, st   # the first round leaves 256 parents of about 15.6 Ki tuples: they fit
+        assert st.get("regpart_rounds", 0) == 0 and st.get("leaf17_segments", 0) == 0
+    elif n == 4_000_000:               # the first round leaves 256 parents of about 15.6 Ki tuples: they fit
+        if leaf17:
+            assert st.get("leaf17_segments", 0) >= 1 and st.get("regpart_rounds", 0) == 0, st
+        else:
+            assert st.get("regpart_rounds", 0) >= 1, st
+
+
+def test_leaf17_duplicates_and_rejected_segments(ctx):
+    """leaf17_kernel's corners: duplicates inside a segment (ties are put in order by the neighbour fix-up) and segments
+    with runs of equal counted bits longer than the fix-up follows (rejected: the register partition + the small leaves
+    finish them)."""
+    import torch
+    rng = np.random.default_rng(77)
+    n = 4_000_001
+    k = rng.integers(0, 1 << 64, n, dtype=np.uint64)                # (256 first-round buckets of about 15.6 Ki tuples: they fit the leaf)
+    k[5::5] = k[4::5][: k[5::5].size]                                # every fifth key repeats its neighbour
+    # one top-byte bucket whose 20 varying bits take only 8 values on their top 13 (the counted ones): thousands of tuples
+    # per counted value, seven more bits to put in order
+    sel = (k >> np.uint64(56)) == np.uint64(9)
+    c = (k[sel] >> np.uint64(20)) & np.uint64(7)
+    k[sel] = (np.uint64(9) << np.uint64(56)) | ((c * np.uint64(0x1249)) & np.uint64(0x1FFF)) << np.uint64(7) | (k[sel] & np.uint64(127))
+    tk, tr = dev(k), torch.arange(n, dtype=torch.int64, device="cuda")
+    ctx.sort_pairs_u64(tk, tr)
+    out, rid = host(tk), tr.cpu().numpy()
+    assert (out == np.sort(k)).all() and (k[rid] == out).all() and (np.sort(rid) == np.arange(n)).all()
+    st = ctx.stats()
+    assert st.get("leaf17_segments", 0) >= 1 and st.get("leaf17_rejected", 0) >= 1, st
 
 
 @pytest.mark.parametrize("regpart", [0, 1])

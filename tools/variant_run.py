@@ -73,6 +73,8 @@ if hasattr(L, "msd_debug_stamps"):
     if name.startswith("lstamps"):  # leaf_count_sort_kernel sections
         NAMES = ["keys wait+OR/AND+clear", "B+merge+B", "fetch-adds", "B+sums+scan+B+prefix", "B+scatter", "descriptor+prefetch", "B+fix-up",
                  "write-back", "-", "loop", "-", "segments"]
+    if name.startswith("l17stamps"):  # leaf17_kernel sections
+        NAMES = ["keys arrive+OR/AND+clear+2B", "fetch-adds", "scan (3B)", "keys into LDS", "long-group check", "fix-up", "payload loads + keys out", "payloads out", "-", "loop", "-", "segments"]
     if name.startswith("cstamps"):  # count_place_kernel sections
         NAMES = ["clear", "B", "fetch-adds", "B", "byte sums", "B+block scan", "prefix", "positions", "B+LDS out+B", "loop", "prefetch+store", "segments"]
     if name.startswith("sstamps"):  # classify_kernel (streaming) sections
