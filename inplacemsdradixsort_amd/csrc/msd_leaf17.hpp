@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 		}
 		k[NK - 1] = kb[min((uint32_t)(NV * TH * 2) + tid, tot - 1u)];
 		auto elem = [&](int u) -> uint32_t { return u < NV * 2 ? (uint32_t)((u / 2) * TH * 2) + tid * 2 + (u % 2) : (uint32_t)(NV * TH * 2) + tid; };
+		(void)elem;
 		// ---- which bits vary (OR / AND over the segment), counters cleared
 		for (uint32_t j = tid; j < ((uint32_t)1 << LB) / 2; j += TH) cw[j] = 0;
 		if (tid == 0) {
@@ -234,49 +235,63 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 			__syncthreads(); // every look-up is done: the staging buffer is free
 		}
 		// ---- keys, then payloads: to their final places in the staging buffer (on the array's 16-byte grid), out as whole vectors
-		auto permute = [&](const uint64_t(&x)[NK], uint64_t *gb, bool stage_holds_it) {
-			if (!stage_holds_it) {
+		auto place = [&](const uint64_t(&x)[NK]) {
 #pragma unroll
-				for (int u = 0; u < NK; ++u) {
-					uint64_t *o = (pr[u] >> 31) ? junk + lane : stage + (pr[u] & 0x7FFFFFFFu) + off;
-					*o = x[u];
-				}
-				__syncthreads();
+			for (int u = 0; u < NK; ++u) {
+				uint64_t *o = (pr[u] >> 31) ? junk + lane : stage + (pr[u] & 0x7FFFFFFFu) + off;
+				*o = x[u];
 			}
+		};
+		auto store_out = [&](uint64_t *gb) {
+			// (an opaque copy of the thread index per use: the nine vector addresses, common to the key loads, the payload
+			// loads and both stores, are otherwise kept in registers across the whole segment -- and spilled)
+			uint32_t tq = tid;
+			asm volatile("" : "+v"(tq));
 			const uint32_t v_first = off, v_end = tot >> 1; // whole vectors: [v_first, v_end)
 #pragma unroll
 			for (int v = 0; v < NV; ++v) {
-				const uint32_t q = (uint32_t)(v * TH) + tid;
+				const uint32_t q = (uint32_t)(v * TH) + tq;
 				if (q >= v_first && q < v_end) reinterpret_cast<u32x4 *>(gb)[q] = reinterpret_cast<const u32x4 *>(stage)[q];
 			}
 			{
-				const uint32_t q = (uint32_t)(NV * TH) + tid; // (at most kL17Cap / 2 - NV * TH = 512 more vectors)
+				const uint32_t q = (uint32_t)(NV * TH) + tq; // (at most kL17Cap / 2 - NV * TH = 512 more vectors)
 				if (q < v_end) reinterpret_cast<u32x4 *>(gb)[q] = reinterpret_cast<const u32x4 *>(stage)[q];
 			}
-			if (tid == 0) { // the single elements at both ends
+			if (tq == 0) { // the single elements at both ends
 				if (off && tot > 1) gb[1] = stage[1];
 				if ((tot & 1u) && tot - 1u >= off && (tot - 1u != 1u || !off)) gb[tot - 1u] = stage[tot - 1u];
 			}
-			__syncthreads();
 		};
 		MSD_STAMP(5); // fix-up
-		// the payloads start travelling while the keys are permuted and stored (loaded before the fix-up -- 34 more registers
-		// held through it -- the kernel spills more and runs 7 % slower: 12.8 against 11.9 ms at 2^30 tuples)
+		// (without groups and with off == 0 the keys already lie at their final places in the staging buffer)
+		if (groups || off != 0) place(k);
+		// The payloads start travelling once the keys have left their registers, i.e. while the keys are stored.  (Loaded
+		// earlier -- before the fix-up, or before the keys' last LDS write -- they are live together with the 34 key
+		// registers: the compiler parks registers in scratch memory, which profiles/pmc_traffic_c5a.json showed as 13 GB of
+		// HBM traffic per launch on top of the 34 GB of tuples, and the kernel runs slower, not faster.)
 		uint64_t r[HV ? NK : 1];
 		if constexpr (HV) {
+			uint32_t tq = tid;
+			asm volatile("" : "+v"(tq));
 #pragma unroll
 			for (int v = 0; v < NV; ++v) {
-				const uint32_t q = min((uint32_t)(v * TH) + tid, lastv) * 2u;
+				const uint32_t q = min((uint32_t)(v * TH) + tq, lastv) * 2u;
 				const u32x4 b = *reinterpret_cast<const u32x4 *>(vb + q);
 				r[2 * v] = (uint64_t)b.x | ((uint64_t)b.y << 32);
 				r[2 * v + 1] = (uint64_t)b.z | ((uint64_t)b.w << 32);
 			}
-			r[NK - 1] = vb[min((uint32_t)(NV * TH * 2) + tid, tot - 1u)];
+			r[NK - 1] = vb[min((uint32_t)(NV * TH * 2) + tq, tot - 1u)];
 		}
-		// (without groups and with off == 0 the keys already lie at their final places in the staging buffer)
-		permute(k, kb, !groups && off == 0);
+		__syncthreads();
+		store_out(kb);
+		__syncthreads();
 		MSD_STAMP(6); // keys out
-		if constexpr (HV) permute(r, vb, false);
+		if constexpr (HV) {
+			place(r);
+			__syncthreads();
+			store_out(vb);
+			__syncthreads();
+		}
 		MSD_STAMP(7); // payloads out
 	}
 	MSD_STAMP_FLUSH(TH / 64);

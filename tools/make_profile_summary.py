@@ -51,11 +51,16 @@ with open(f"profiles/{rnd}_pmc_traffic{sfx}.csv", "w") as o:
     o.write("kernel,launches,FETCH_SIZE_sum_KiB_raw,WRITE_SIZE_sum_KiB,read_bytes_per_launch_corrected_x2,write_bytes_per_launch\n")
     for r in rows:
         o.write(",".join(str(x) for x in r) + "\n")
+import subprocess
+sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?"
+dirty = bool(subprocess.run(["git", "status", "--porcelain", "--", "inplacemsdradixsort_amd", "bench.py"], capture_output=True, text=True).stdout.strip())
+js["__meta__"] = {"git_sha": sha + ("+" if dirty else ""), "round": rnd, "config": cfg,
+                  "collected_by": "tools/profile_bench.sh (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"}
 json.dump(js, open(f"profiles/pmc_traffic{sfx}.json", "w"), indent=1)
 for row in csv.DictReader(open(st)):
     if float(row["Percentage"]) > 0.5:
         print(f"{short(row['Name'])[:46]:46s} calls={row['Calls']:>4} avg_us={float(row['AverageNs'])/1e3:10.1f} pct={row['Percentage']}")
 print(f"per sort: {per_sort/1e9:.2f} GB")
 for k, v in js.items():
-    if k != "__per_sort__" and v["hbm_bytes_per_launch"] > 1e8:
+    if not k.startswith("__") and v["hbm_bytes_per_launch"] > 1e8:
         print(f"{k[:46]:46s} HBM read {v['hbm_read_bytes_per_launch']/1e9:7.2f} GB  write {v['hbm_write_bytes_per_launch']/1e9:7.2f} GB per launch")
