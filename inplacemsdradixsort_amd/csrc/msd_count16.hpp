@@ -59,7 +59,9 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 	// memory or LDS they would make every address a per-lane 64-bit computation)
 	auto uniform = [](Segment g) -> Segment {
 		Segment u;
-		// (the builtin returns a signed int: without the cast to uint32_t a low word >= 2^31 would sign-extend)
+		// (the builtin returns a signed int: without the cast to uint32_t a low word >= 2^31 sign-extends into the high
+		// word -- element offsets that large exist only in arrays of more than 2^31 keys.  THIS was round 2's GPU fault
+		// at 2^32 keys: `keys + start` pointed 16 GiB below the array and the segment's first 16-byte load faulted.)
 		auto rfl = [](uint32_t x) -> uint64_t { return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(x); };
 		u.start = rfl((uint32_t)g.start) | (rfl((uint32_t)(g.start >> 32)) << 32);
 		u.count = rfl((uint32_t)g.count) | (rfl((uint32_t)(g.count >> 32)) << 32);
@@ -79,7 +81,9 @@ __global__ __launch_bounds__(kC16Th, (kC16Th >= 1024 ? 8 : 4)) void count_place1
 		const uint32_t off = (uint32_t)(g.start & 3u);
 		const uint32_t *base = keys + (g.start - off);
 		const uint64_t tot = g.count + off;
-		// (the last vector of the array's last segment may reach beyond the array: such a segment is not taken)
+		// (the only other access of this kernel that can leave the array: the 16-byte vector holding the LAST elements of
+		// the array's last segment may extend up to 12 bytes behind the allocation -- such a segment is not taken, n_total
+		// is the array's length)
 		const bool take = g.bits >= kC16MinBits && g.bits <= 16 && tot <= (uint64_t)kC16Cap && ((g.start - off + tot + 3) & ~3ull) <= n_total;
 		const uint32_t totc = take ? (uint32_t)tot : 1u;
 		const uint32_t lastv = (totc - 1u) >> 2;

@@ -2111,13 +2111,16 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 			const K lowmask = shift ? ((K)1 << shift) - 1 : (K)0;
 			const bool groups = shift && (vopen & lowmask) != 0; // more bits vary than were counted
 			constexpr uint32_t kMaxGroup = 48;
+			// (same group <=> the keys agree above `shift` <=> their XOR is below 2^shift: one compare against a uniform bound
+			// instead of two shifts -- 64-bit shifts run at a quarter of the rate)
+			const K glim = (K)1 << shift;
 			if (groups) {
 				// a group (elements equal on the counted bits; contiguous by now) longer than kMaxGroup sends the untouched
 				// segment to the general LDS sort: with the groups in order, two elements kMaxGroup apart share a group
 				// only if the group is longer than that
 				bool too_long = false;
 				for (uint32_t i = tid; i + kMaxGroup < n; i += TH)
-					if ((xk[i] >> shift) == (xk[i + kMaxGroup] >> shift)) too_long = true;
+					if ((K)(xk[i] ^ xk[i + kMaxGroup]) < glim) too_long = true;
 				if (too_long) wtot[16] = 1;
 				__syncthreads();
 				bad = wtot[16] != 0;
@@ -2135,7 +2138,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 				constexpr uint32_t WIN = 3;
 #pragma unroll 1
 				for (uint32_t idx = tid; idx < n; idx += TH) {
-					const K me = xk[idx], hi = me >> shift;
+					const K me = xk[idx];
 					K lk[WIN], rkk[WIN];
 #pragma unroll
 					for (uint32_t d = 0; d < WIN; ++d) {
@@ -2146,17 +2149,17 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 					bool ml = true, mr = true;
 #pragma unroll
 					for (uint32_t d = 0; d < WIN; ++d) {
-						ml = ml && idx > d && (lk[d] >> shift) == hi;      // members to the left: those <= me come first
+						ml = ml && idx > d && (K)(lk[d] ^ me) < glim;      // members to the left: those <= me come first
 						before += ml && lk[d] <= me ? 1u : 0u;
 						left += ml ? 1u : 0u;
-						mr = mr && idx + d + 1 < n && (rkk[d] >> shift) == hi; // members to the right: those < me come first
+						mr = mr && idx + d + 1 < n && (K)(rkk[d] ^ me) < glim; // members to the right: those < me come first
 						before += mr && rkk[d] < me ? 1u : 0u;
 						right += mr ? 1u : 0u;
 					}
 					if (ml) { // the group goes on beyond the window
 						while (idx > left) {
 							const K o = xk[idx - left - 1];
-							if ((o >> shift) != hi) break;
+							if ((K)(o ^ me) >= glim) break;
 							before += o <= me ? 1u : 0u;
 							++left;
 						}
@@ -2164,7 +2167,7 @@ __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K
 					if (mr) {
 						for (uint32_t e = idx + right + 1; e < n; ++e) {
 							const K o = xk[e];
-							if ((o >> shift) != hi) break;
+							if ((K)(o ^ me) >= glim) break;
 							before += o < me ? 1u : 0u;
 						}
 					}

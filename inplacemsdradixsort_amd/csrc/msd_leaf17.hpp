@@ -169,10 +169,13 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 		const bool groups = shift && (vopen & lowmask) != 0; // more bits vary than were counted
 		bool bad = false;
 		if (groups) { // (uniform)
+			// (same group <=> the keys agree above `shift` <=> their XOR is below 2^shift: one 64-bit compare against a uniform
+			// bound instead of two 64-bit shifts, which run at a quarter of the rate)
+			const uint64_t glim = 1ull << shift;
 			// two elements kL17MaxGroup apart share a group only if the group is longer than that
 			bool too_long = false;
 			for (uint32_t i = tid; i + kL17MaxGroup < n; i += TH)
-				if ((stage[i] >> shift) == (stage[i + kL17MaxGroup] >> shift)) too_long = true;
+				if ((stage[i] ^ stage[i + kL17MaxGroup]) < glim) too_long = true;
 			if (too_long) wtot[16] = 1;
 			__syncthreads();
 			bad = wtot[16] != 0;
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 			constexpr uint32_t WIN = 3;
 #pragma unroll 1
 			for (uint32_t idx = tid; idx < n; idx += TH) {
-				const uint64_t me = stage[idx], hi = me >> shift;
+				const uint64_t me = stage[idx];
 				uint64_t lk[WIN], rk[WIN];
 #pragma unroll
 				for (uint32_t d = 0; d < WIN; ++d) {
@@ -202,17 +205,17 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 				bool ml = true, mr = true;
 #pragma unroll
 				for (uint32_t d = 0; d < WIN; ++d) {
-					ml = ml && idx > d && (lk[d] >> shift) == hi;          // members to the left: those <= me come first
+					ml = ml && idx > d && (lk[d] ^ me) < glim;             // members to the left: those <= me come first
 					before += ml && lk[d] <= me ? 1u : 0u;
 					left += ml ? 1u : 0u;
-					mr = mr && idx + d + 1 < n && (rk[d] >> shift) == hi;  // members to the right: those < me come first
+					mr = mr && idx + d + 1 < n && (rk[d] ^ me) < glim;     // members to the right: those < me come first
 					before += mr && rk[d] < me ? 1u : 0u;
 					right += mr ? 1u : 0u;
 				}
 				if (ml) { // the group goes on beyond the window
 					while (idx > left) {
 						const uint64_t o = stage[idx - left - 1];
-						if ((o >> shift) != hi) break;
+						if ((o ^ me) >= glim) break;
 						before += o <= me ? 1u : 0u;
 						++left;
 					}
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 				if (mr) {
 					for (uint32_t e = idx + right + 1; e < n; ++e) {
 						const uint64_t o = stage[e];
-						if ((o >> shift) != hi) break;
+						if ((o ^ me) >= glim) break;
 						before += o < me ? 1u : 0u;
 					}
 				}
