@@ -316,41 +316,24 @@ def make_workload(ctx, torch, config_id, rank, n):
     return cfg, pairs, (torch.int32 if cfg["key"] == 4 else torch.int64), gen, sort
 
 
-def run_other_config(ctx, torch, config_id, logn, steps=3, warmup=1):
-    """One more single-GPU config inside the default run: `steps` timed sorts of fresh inputs (one
-    buffer, regenerated before every step outside the clock), every one verified by the library's check AND the
-    independent torch reduction; then one profiled sort for the dominant kernel."""
-    n = 1 << logn
-    cfg, pairs, tdt, gen, sort = make_workload(ctx, torch, config_id, 0, n)
-    t = torch.empty(n, dtype=tdt, device="cuda")
-    r = torch.empty(n, dtype=tdt, device="cuda") if pairs else None
-    ctx.reserve(n + n // 8, cfg["key"], cfg["val"])
-    ms, verified = [], True
-    for s in range(warmup + steps):
-        gen(t, 200 + s)
-        if pairs:
-            r.copy_(t)                      # rid = key, the reference's check(..., same=1) convention
-        c0 = ctx.check(t)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        sort(t, r)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        if s >= warmup:
-            ms.append(dt * 1e3)
-            v, s_, x_ = ctx.check(t, r) if pairs else ctx.check(t)
-            tv, ts, tm = torch_check(torch, t, r)
-            verified &= (v == 0 and s_ == c0[1] and x_ == c0[2] and tv == 0 and ts == c0[1] and tm == 0)
-    roofline, real = profile_one_sort(ctx, torch, cfg, config_id, n, gen, sort, t, r)
-    sec = sum(ms) / len(ms) * 1e-3
-    unit = "Gtuples/s" if pairs else "Gkeys/s"
-    out = {"workload": f"2^{logn} {cfg['title']}", "ms_per_step": round(sec * 1e3, 3), "steps": steps, "ms_each": [round(x, 3) for x in ms],
-           "value": round(n / sec / 1e9, 3), "unit": unit, "dtype": cfg["dtype"], "verified": bool(verified),
-           "whole_sort": whole_sort_block(cfg, n, sec, real), "roofline": roofline}
-    out["whole_sort"].pop("note", None)
-    del t, r
-    torch.cuda.empty_cache()
-    return out
+def run_other_config(config_id, logn, steps=3, warmup=1):
+    """One more single-GPU config inside the default run: `bench.py --config <id>` itself, as a child
+    process (its own HIP context: a failure there cannot take the headline line with it), with `steps` timed sorts -- every
+    one verified by the library's check AND the independent torch reduction -- and one profiled sort for the dominant
+    kernel.  Returns the fields of its line that matter here."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", config_id, "--logn", str(logn), "--steps", str(steps), "--warmup", str(warmup),
+           "--no-cpu-baseline", "--no-other-configs"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"exit code {p.returncode}: {p.stderr.strip()[-300:]}"}
+    d = json.loads(lines[-1])
+    ws = d["whole_sort"]
+    ws.pop("note", None)
+    return {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "value": d["value"], "unit": d["unit"],
+            "dtype": d["dtype"], "verified": d["config"]["verified"], "steps_verified": d["config"]["steps_verified"], "whole_sort": ws,
+            "roofline": d["roofline"]}
 
 
 def main():
@@ -584,12 +567,13 @@ def main():
     }
     # ---- the other single-GPU configs in the same record (default run only): headline buffers are freed first
     if N == 1 and args.config == "c2" and not args.no_other_configs and args.logn == 30:
-        del bufs, rids, outs
+        a = b = None
+        del bufs, rids, outs, a, b
         torch.cuda.empty_cache()
         others = {}
         for cid in ("c3", "c5a", "c5b"):
             try:
-                others[cid] = run_other_config(ctx, torch, cid, args.logn)
+                others[cid] = run_other_config(cid, args.logn)
             except Exception as e:  # a failing side config must not take the headline line with it
                 others[cid] = {"error": f"{type(e).__name__}: {e}"}
         out["other_configs"] = others

@@ -463,6 +463,28 @@ def test_reference_api_rewrites_size_at_key_boundaries():
         assert 0.6 * tm[9] <= sum(tm[:9]) <= 1.05 * tm[9] + 2000, tm
 
 
+def _independent_check(t, rids=None, chunk=1 << 26):
+    """(order violations, key sum mod 2^64, key != rid) by chunked torch reductions -- independent of the library's own
+    check kernel (the full-size tests relied on msd_check_* alone).  u32 / u64 bit patterns in int32 / int64."""
+    import torch
+    n, viol, total, mism, prev = t.numel(), 0, 0, 0, None
+    for a in range(0, n, chunk):
+        c = t[a:a + chunk]
+        if t.element_size() == 4:
+            u = c.to(torch.int64) & 0xFFFFFFFF
+            total += int(u.sum().item())
+        else:
+            u = c ^ (-(1 << 63))                     # unsigned order as signed order
+            total += int(c.sum().item())             # (wraps like the device's sum)
+        viol += int((u[1:] < u[:-1]).sum().item())
+        if prev is not None and int(u[0].item()) < prev:
+            viol += 1
+        prev = int(u[-1].item())
+        if rids is not None:
+            mism += int((c != rids[a:a + chunk]).sum().item())
+    return viol, total & ((1 << 64) - 1), mism
+
+
 @pytest.mark.parametrize("logn,kind", [(26, "uniform"), (26, "zipf"), (30, "uniform"), (30, "zipf"), (32, "uniform")])
 def test_full_size_properties(ctx, logn, kind):
     """BASELINE.json configs[1], [2] at full size: sorted, checksums preserved, idempotent."""
@@ -475,6 +497,7 @@ def test_full_size_properties(ctx, logn, kind):
     ctx.sort_u32(t)
     v, s, x = ctx.check(t)
     assert (v, s, x) == (0, s0, x0)
+    assert _independent_check(t) == (0, s0, 0)          # the same verdict without the library's check kernel
     if logn <= 26:
         first = t.clone()
         ctx.sort_u32(t)  # idempotence
@@ -504,6 +527,7 @@ def test_pairs_at_baseline_size(ctx, shr, name):
     st = ctx.stats()
     v, s, x = ctx.check(k, r)  # order + key == rid
     assert (v, s, x) == (0, s0, x0)
+    assert _independent_check(k, r) == (0, s0, 0)       # order, sum and key == rid without the library's check kernel
     assert st.get("direct_rounds", 0) >= 2, st
     if shr:
         assert st.get("skipped_bits", 0) == 32, st

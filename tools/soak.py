@@ -54,6 +54,9 @@ for c in range(cases):
     if not os.environ.get("SOAK_DEFAULT_OPTS"):
         ctx.set_option("count16", int(torch.randint(0, 3, (1,)).item()))
         ctx.set_option("regpart", int(torch.randint(0, 4, (1,)).item() != 0))
+        ctx.set_option("leaf17", int(torch.randint(0, 4, (1,)).item() != 0))          # round 3's kernels: mostly on
+        ctx.set_option("mid_leaf", int(torch.randint(0, 4, (1,)).item() != 0))
+        ctx.set_option("stream_kernel", 2 if int(torch.randint(0, 4, (1,)).item()) != 0 else 1)
         ctx.set_option("direct_min", 1 << int(torch.randint(14, 27, (1,)).item()))
         ctx.set_option("direct_min_parent", 1 << int(torch.randint(10, 18, (1,)).item()))
     x = make(kind, n, bits)
