@@ -42,6 +42,10 @@ typedef struct msd_shard msd_shard;
  * nccl_comm == NULL: a single rank (no communicator needed; the calls below then sort locally). */
 int msd_shard_create(msd_shard **out, msd_ctx *ctx, void *nccl_comm);
 int msd_shard_destroy(msd_shard *sh);
+/* "force_exchange" (tests): 1 = a single rank WITH a communicator runs the whole exchange -- count all-gather, grouped
+ * send / receive to itself, the leaf over the "arrived" extents -- instead of sorting locally: all of the N > 1 code that
+ * one GPU can execute through RCCL. */
+int msd_shard_set_option(msd_shard *sh, const char *name, int64_t value);
 int msd_shard_rank(const msd_shard *sh);
 int msd_shard_world(const msd_shard *sh);
 const char *msd_shard_last_error(const msd_shard *sh);

@@ -32,7 +32,7 @@ EXPORTS = [
 ]
 
 # every symbol include/msd_sharded_hip.h declares (libinpmsdradix_hip_rccl.so)
-RCCL_EXPORTS = ["msd_shard_create", "msd_shard_destroy", "msd_shard_rank", "msd_shard_world", "msd_shard_last_error",
+RCCL_EXPORTS = ["msd_shard_create", "msd_shard_destroy", "msd_shard_set_option", "msd_shard_rank", "msd_shard_world", "msd_shard_last_error",
                 "msd_sort_u32_sharded", "msd_sort_pairs_u64_sharded", "msd_sort_u32_multi"]
 
 _lib = None
@@ -150,6 +150,7 @@ def load_rccl(build_if_missing: bool = True) -> C.CDLL:
     _vpp = C.POINTER(_vp)
     L.msd_shard_create.argtypes = [_vpp, _vp, _vp]
     L.msd_shard_destroy.argtypes = [_vp]
+    L.msd_shard_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
     L.msd_shard_rank.argtypes = [_vp]
     L.msd_shard_world.argtypes = [_vp]
     L.msd_shard_last_error.argtypes = [_vp]

@@ -302,6 +302,9 @@ class MsdShard:
         if rc != 0:
             raise MsdError(f"error {rc}: {self._L.msd_shard_last_error(self._h).decode()}")
 
+    def set_option(self, name: str, value: int) -> None:
+        self._ok(self._L.msd_shard_set_option(self._h, name.encode(), int(value)))
+
     def sort_u32(self, keys, recv, work=None, scheme: Optional[str] = None):
         """``msd_sort_u32_sharded``: returns this rank's sorted key range -- a view of ``work`` (fine scheme), ``recv``
         (coarse) or ``keys`` (single rank)."""

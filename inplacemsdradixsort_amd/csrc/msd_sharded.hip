@@ -34,6 +34,7 @@ struct msd_shard {
 	// device scratch: [own counts | capacity | n][all ranks' rows][send matrix + capacities + sizes][mine: world x buckets / world]
 	uint64_t *d_row = nullptr, *d_all = nullptr, *d_small = nullptr, *d_mine = nullptr, *d_bounds = nullptr;
 	uint64_t *h_small = nullptr; // pinned
+	bool force_exchange = false; // (tests) a single rank with a communicator goes through the whole exchange instead of sorting locally
 	std::string err;
 };
 
@@ -227,6 +228,16 @@ int msd_shard_destroy(msd_shard *sh)
 	return MSD_OK;
 }
 
+int msd_shard_set_option(msd_shard *sh, const char *name, int64_t value)
+{
+	if (!sh || !name) return MSD_EINVAL;
+	if (!strcmp(name, "force_exchange")) {
+		sh->force_exchange = value != 0;
+		return MSD_OK;
+	}
+	return fail(sh, MSD_EINVAL, "unknown option %s", name);
+}
+
 int msd_shard_rank(const msd_shard *sh) { return sh ? sh->rank : -1; }
 int msd_shard_world(const msd_shard *sh) { return sh ? sh->world : 0; }
 const char *msd_shard_last_error(const msd_shard *sh) { return sh ? sh->err.c_str() : "null shard"; }
@@ -240,7 +251,7 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 	SH_HIP(sh, hipSetDevice(sh->device));
 	sh->stream = (hipStream_t)msd_get_stream(sh->ctx);
 	const int W = sh->world, lg = log2_exact(W);
-	if (W == 1) {
+	if (W == 1 && !(sh->force_exchange && sh->comm)) {
 		SH_MSD(sh, msd_sort_u32(sh->ctx, d_keys, n));
 		SH_HIP(sh, hipStreamSynchronize(sh->stream));
 		*d_out = d_keys;
@@ -315,7 +326,7 @@ int msd_sort_pairs_u64_sharded(msd_shard *sh, uint64_t *d_keys, uint64_t *d_rids
 	SH_HIP(sh, hipSetDevice(sh->device));
 	sh->stream = (hipStream_t)msd_get_stream(sh->ctx);
 	const int W = sh->world, lg = log2_exact(W);
-	if (W == 1) {
+	if (W == 1 && !(sh->force_exchange && sh->comm)) {
 		SH_MSD(sh, msd_sort_pairs_u64(sh->ctx, d_keys, d_rids, n));
 		SH_HIP(sh, hipStreamSynchronize(sh->stream));
 		*d_out_keys = d_keys;

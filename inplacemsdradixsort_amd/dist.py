@@ -130,11 +130,11 @@ FINE_BITS = 16          # the fine scheme orders a shard by its top 16 bits befo
 FINE_MIN_KEYS = 1 << 27  # ... when a rank holds at least this many keys (buckets of >= 2^11 keys per source)
 
 
-def use_fine(n_keys: int, world: int, have_work: bool, scheme=None) -> bool:
+def use_fine(n_keys: int, world: int, have_work: bool, scheme=None, _force_exchange: bool = False) -> bool:
     """Which scheme ``sort_sharded_u32`` / ``ShardedSorter`` take: ``scheme`` "fine" / "coarse" forces one (tests,
     experiments); by default the fine scheme runs when there is a second buffer, 2..8 ranks and a large shard.  Every
     rank must come to the same answer: shards of one call should be equally long (they are in bench.py)."""
-    if scheme == "coarse" or world < 2 or not have_work:
+    if scheme == "coarse" or (world < 2 and not _force_exchange) or not have_work:
         return False
     if scheme == "fine":
         return True
@@ -209,7 +209,7 @@ def bucket_major(mine):
     return src_off, dst_off, lens, seg_off
 
 
-def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None, scheme=None):
+def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None, scheme=None, _force_exchange: bool = False):
     """Sorts the union of all ranks' ``keys`` (int32 tensors holding u32 bit patterns).
     Returns this rank's sorted range; rank r's range precedes rank r+1's.
 
@@ -222,10 +222,10 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
     one launch and sorted there as segments on the remaining 24 bits -- the result is a view of ``work``.  Without it
     the received keys are sorted in ``recv`` on all ``32 - log2(world)`` bits."""
     lg = _log2(world)
-    if world == 1:
+    if world == 1 and not _force_exchange:   # (_force_exchange: tests run the whole exchange over a one-rank process group)
         engine.sort_u32(keys)
         return keys
-    if use_fine(keys.numel(), world, work is not None, scheme):
+    if use_fine(keys.numel(), world, work is not None, scheme, _force_exchange):
         send_l, got_l, mine = exchange_fine_counts(dist, _fine_counts(engine, keys), min(recv.numel(), work.numel()), world, group)
         m = int(sum(got_l))
         dist.all_to_all_single(recv[:m], keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
@@ -305,13 +305,14 @@ class ShardedSorter:
     untouched until the matching ``collect`` returns.
     """
 
-    def __init__(self, engine, dist, world: int, recv_bufs, group=None, work_bufs=None, scheme=None):
+    def __init__(self, engine, dist, world: int, recv_bufs, group=None, work_bufs=None, scheme=None, _force_exchange: bool = False):
         self.engine, self.dist, self.world, self.group = engine, dist, world, group
         self.scheme = scheme              # None: by shard size (use_fine); "fine" / "coarse": forced
+        self._force = _force_exchange     # (tests) one rank goes through the whole exchange
         self.fine_work = list(work_bufs) if work_bufs else []   # the fine scheme uses the work buffers at any rank count
         self.lg = _log2(world)
         self.recv = list(recv_bufs)
-        if world > 1 and len(self.recv) < 2:
+        if (world > 1 or _force_exchange) and len(self.recv) < 2:
             raise ValueError("ShardedSorter needs two receive buffers")
         # work buffers: the arrived runs are gathered bucket-major into one of them and sorted there as segments on
         # 24 bits (the local sort does not repeat the top-digit pass); collect() then returns a view of a WORK buffer,
@@ -342,13 +343,13 @@ class ShardedSorter:
         return None
 
     def submit(self, keys) -> None:
-        if self.world == 1:
+        if self.world == 1 and not self._force:
             self._pending.append((keys, None, None))
             return
         if len(self._pending) >= len(self.recv):
             raise RuntimeError("collect() before submitting more shards than there are receive buffers")
         recv = self.recv[self._slot]
-        if use_fine(keys.numel(), self.world, bool(self.fine_work), self.scheme):
+        if use_fine(keys.numel(), self.world, bool(self.fine_work), self.scheme, self._force):
             cap = min(recv.numel(), min(w.numel() for w in self.fine_work))
             send_l, got_l, mine = exchange_fine_counts(self.dist, _fine_counts(self.engine, keys), cap, self.world, self.group)  # raises on all ranks
             self._slot = (self._slot + 1) % len(self.recv)
@@ -377,7 +378,7 @@ class ShardedSorter:
             self._wslot = (self._wslot + 1) % len(self.fine_work)
             return _fine_finish(self.engine, recv, final, counts, got_l, _rank(self.dist, self.group), self.world)
         if mine is None:
-            if self.world > 1:
+            if self.world > 1 or self._force:
                 self.engine.sort_u32(out, end_bit=32 - self.lg)
             else:
                 self.engine.sort_u32(out)

@@ -100,3 +100,109 @@ def test_bad_arguments(ctx, comm1):
     devs = (C.c_int * 3)(0, 0, 0)
     assert R.msd_sort_u32_multi(3, devs, None, None, None, 0, None, 0, 0, None, None) != 0   # not a power of two / null arrays
     sh.close()
+
+
+@pytest.mark.parametrize("scheme", ["fine", "coarse"])
+@pytest.mark.parametrize("n", [(1 << 20) + 3, 1 << 24])
+def test_whole_exchange_through_rccl_on_one_rank(ctx, comm1, scheme, n):
+    """msd_shard_set_option("force_exchange"): the single rank does NOT take the local shortcut -- top-digit passes,
+    bucket boundaries, ncclAllGather of the counts, the send-matrix kernels, ncclGroupStart / ncclSend / ncclRecv to
+    itself / ncclGroupEnd, and the leaf over the arrived extents (fine) or the sort of what arrived (coarse) all run,
+    through a real RCCL communicator: everything of the N > 1 path that one GPU can execute."""
+    import torch
+    from inplacemsdradixsort_amd import MsdShard
+    from oracle import oracle as O
+    sh = MsdShard(ctx, comm1)
+    sh.set_option("force_exchange", 1)
+    k = O.gen_uniform_u32(n, seed=n + len(scheme))
+    t = dev(k)
+    recv = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
+    work = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
+    out = sh.sort_u32(t, recv, work, scheme=scheme)
+    assert out.data_ptr() == (work if scheme == "fine" else recv).data_ptr() and out.numel() == n
+    assert (host(out, np.uint32) == O.sort_u32(k)).all()
+    # tuples (coarse scheme: keys and rids in one group of sends and receives)
+    m = n // 4
+    k64 = O.gen_uniform_u64(m, seed=m)
+    tk, tr = dev(k64), dev(k64 ^ np.uint64(0x5A5A5A5A5A5A5A5A))
+    rk = torch.empty(m + 16, dtype=torch.int64, device="cuda")
+    rr = torch.empty(m + 16, dtype=torch.int64, device="cuda")
+    ok, orr = sh.sort_pairs_u64(tk, tr, rk, rr)
+    assert ok.data_ptr() == rk.data_ptr() and ok.numel() == m
+    assert (host(ok, np.uint64) == O.sort_u64(k64)).all()
+    assert (host(orr, np.uint64) == (host(ok, np.uint64) ^ np.uint64(0x5A5A5A5A5A5A5A5A))).all()
+    # a receive buffer that is too small: MSD_EOVERFLOW before anything is exchanged
+    from inplacemsdradixsort_amd.dist import ReceiveOverflow
+    with pytest.raises(ReceiveOverflow):
+        sh.sort_u32(dev(k), recv[: n // 2], work, scheme=scheme)
+    sh.close()
+
+
+def _nccl_worker(port, q):
+    """torch.distributed with backend "nccl" (= RCCL) and ONE rank: dist.py's exchange code -- all_gather, the asynchronous
+    all_to_all_single and its Work handle, the pipelined ShardedSorter -- on the real backend, and the C entry point on the
+    communicator torch has set up."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from inplacemsdradixsort_amd import MsdContext, MsdShard, torch_nccl_comm
+    from inplacemsdradixsort_amd.dist import ShardedSorter, sort_sharded_u32
+    from oracle import oracle as O
+    res = {}
+    try:
+        ctx = MsdContext(0)
+        ctx.use_torch_stream()
+        n = (1 << 22) + 5
+        for scheme in ("fine", "coarse"):
+            k = O.gen_uniform_u32(n, seed=7)
+            t = dev(k)
+            recv = torch.empty(n + 64, dtype=torch.int32, device="cuda")
+            work = torch.empty(n + 64, dtype=torch.int32, device="cuda")
+            out = sort_sharded_u32(ctx, t, recv, dist, 1, work=work, scheme=scheme, _force_exchange=True)
+            res["oneshot " + scheme] = bool((host(out, np.uint32) == O.sort_u32(k)).all())
+            # the pipelined form bench.py --gpus N times: exchange of shard s in flight while shard s - 1 is finished
+            shards = [dev(O.gen_uniform_u32(n, seed=20 + s)) for s in range(3)]
+            sorter = ShardedSorter(ctx, dist, 1, [torch.empty(n + 64, dtype=torch.int32, device="cuda") for _ in range(2)],
+                                   work_bufs=[torch.empty(n + 64, dtype=torch.int32, device="cuda") for _ in range(3)], scheme=scheme,
+                                   _force_exchange=True)
+            outs = []
+            for s in range(3):
+                sorter.submit(shards[s])
+                if s:
+                    outs.append(host(sorter.collect(), np.uint32).copy())
+            outs.append(host(sorter.collect(), np.uint32).copy())
+            res["pipelined " + scheme] = all((outs[s] == O.sort_u32(O.gen_uniform_u32(n, seed=20 + s))).all() for s in range(3))
+        # the C entry point on torch's own communicator
+        dist.barrier()
+        sh = MsdShard(ctx, torch_nccl_comm(0))
+        sh.set_option("force_exchange", 1)
+        k = O.gen_uniform_u32(n, seed=9)
+        out = sh.sort_u32(dev(k), torch.empty(n + 64, dtype=torch.int32, device="cuda"), torch.empty(n + 64, dtype=torch.int32, device="cuda"), scheme="fine")
+        res["native on torch's communicator"] = bool((host(out, np.uint32) == O.sort_u32(k)).all()) and (sh.rank, sh.world) == (0, 1)
+        sh.close()
+        ctx.close()
+    except Exception as e:  # report instead of hanging the parent
+        res["exception"] = f"{type(e).__name__}: {e}"
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_dist_py_over_the_nccl_backend_on_one_rank():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    p = mpc.Process(target=_nccl_worker, args=(port, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert "exception" not in res, res
+    assert len(res) == 5 and all(res.values()), res
