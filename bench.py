@@ -93,6 +93,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="headline only (the default c2 run also times c3, c5a, c5b)")
     ap.add_argument("--scheme", choices=["fine", "coarse"], default=None, help="N > 1: force the sharding scheme (dist.use_fine)")
+    ap.add_argument("--compute-stream", choices=["pool", "high", "default"], default="high",
+                    help="N > 1: the stream the local work runs on: a stream of its own (pool; high = with high priority) or torch's default stream")
+    ap.add_argument("--one-rank-exchange", action="store_true",
+                    help="REHEARSAL on one GPU with the real RCCL backend: a single rank runs the N > 1 loop -- pre-exchange pass, count "
+                         "exchange, asynchronous all-to-all to itself, counting leaf, pipelined -- instead of the plain sort "
+                         "(start it like an N > 1 run: torch.distributed.run --nproc-per-node 1); the exchange is a device-local "
+                         "copy, so the line says nothing about xGMI")
     ap.add_argument("--cpu-logn", type=int, default=None, help="log2 tuples for the reference's 64-thread sort() "
                     "(default: 30 when the host has the memory for it, else 28)")
     ap.add_argument("--cpu-logn-1t", type=int, default=27, help="log2 keys for the single-thread core")
@@ -338,6 +345,12 @@ def run_other_config(config_id, logn, steps=3, warmup=1):
 
 def main():
     args = parse()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.one_rank_exchange:
+        # HIP multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; with the default the compute stream and
+        # RCCL's stream shared one queue on the GPU box and the exchange ran strictly BETWEEN the compute kernels (one-rank
+        # rehearsal: 14.1 ms per step = the sum of its parts; with 8 queues, or a high-priority compute stream, 12.2).
+        # Must be set before the HIP runtime starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from inplacemsdradixsort_amd import MsdContext
@@ -349,21 +362,30 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     N = world
-    if N > 1 and CONFIGS[args.config]["dtype"] != "u32":
+    multi = N > 1 or args.one_rank_exchange      # the sharded loop runs (one rank: rehearsal over the real backend)
+    if multi and CONFIGS[args.config]["dtype"] != "u32":
         raise SystemExit("the multi-GPU path shards u32 keys (configs c2 / c3)")
-    rehearsal = N > 1 and args.backend == "gloo"
+    rehearsal = (N > 1 and args.backend == "gloo") or args.one_rank_exchange
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if N > 1:
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
+        if rehearsal and args.backend == "gloo":
             import torch.distributed as tdist
             from inplacemsdradixsort_amd.dist import HostStagedDist
             tdist.init_process_group("gloo")
             dist = HostStagedDist(tdist)
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # N > 1: the local work runs on a stream of its own, not on the default stream.  HIP multiplexes streams onto a few
+    # hardware queues; on the GPU box the default stream and the stream RCCL launches its kernels on shared ONE queue, and
+    # the exchange ran strictly between the compute kernels instead of under them (rocprofv3 kernel trace of the one-rank
+    # rehearsal, profiles/r03_onerank_trace_*.txt).  --compute-stream default restores the old behaviour for comparison.
+    side = None
+    if multi and args.compute_stream != "default":
+        side = torch.cuda.Stream(device=local_rank, priority=-1 if args.compute_stream == "high" else 0)
+        torch.cuda.set_stream(side)
     ctx = MsdContext(local_rank)
     ctx.use_torch_stream()
     n = 1 << args.logn
@@ -386,20 +408,20 @@ def main():
     # per timed step when the memory allows, so that EVERY timed step's output is still there when the clock has stopped
     # and is verified.  Coarse scheme (small shards): round 2's path (gather + segmented sort at <= 4 ranks, sort on
     # 32 - log2 N bits where the keys arrived at 8).
-    fine = N > 1 and use_fine(n, N, True, args.scheme)
+    fine = multi and use_fine(n, N, True, args.scheme, args.one_rank_exchange)
     cap = n + n // 8
     nkeep = 0
     recv = work = None
-    if N > 1:
+    if multi:
         free_b, _ = torch.cuda.mem_get_info()
         nkeep = int(max(2, min(K, 24, (free_b - (6 << 30)) // (cap * 4) - 2)))
         gathered = fine or N <= 4
         recv = [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(2 if gathered else nkeep)]
         work = [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(nkeep)] if gathered else None
-    sorter = ShardedSorter(ctx, dist, N, recv, work_bufs=work, scheme=args.scheme) if N > 1 else None
+    sorter = ShardedSorter(ctx, dist, N, recv, work_bufs=work, scheme=args.scheme, _force_exchange=args.one_rank_exchange) if multi else None
 
     def run_steps(lo, hi):
-        if N == 1:
+        if not multi:
             for i in range(lo, hi):
                 sort(bufs[i], rids[i])
             return [(i, bufs[i]) for i in range(lo, hi)]
@@ -414,24 +436,24 @@ def main():
 
     run_steps(0, W)
     torch.cuda.synchronize()
-    if N > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     outs = run_steps(W, W + K)
     torch.cuda.synchronize()
-    if N > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if N > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
     # ---- verify the timed steps' outputs (outside the clock): the library's check kernel AND an independent torch reduction
-    verified, steps_verified = True, 0
-    if N == 1:
+    verified, steps_verified, fail_detail = True, 0, []
+    if not multi:
         for i, o in outs:
             v, s_, x_ = ctx.check(o, rids[i]) if pairs else ctx.check(o)   # pairs: order and key == rid
             tv, ts, tm = torch_check(torch, o, rids[i] if pairs else None)
@@ -472,13 +494,16 @@ def main():
                     ok &= (r_[10] >> (32 - lg)) == g and (r_[11] >> (32 - lg)) == g and r_[10] > prev
                     prev = r_[11]
             verified &= bool(ok)
+            if not ok:   # say what failed (rank 0's view), for the record
+                fail_detail.append({"step": i, "violations_per_rank": [r_[0] for r_ in R], "keys_out": sum(r_[1] for r_ in R), "keys_in": N * n,
+                                    "sum_ok": s_out == s_in, "xor_ok": x_out == x_in, "first_last_per_rank": [(r_[10], r_[11]) for r_ in R]})
             steps_verified += 1
         flag = torch.tensor([1 if verified else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         verified = bool(flag.item())
 
-    roofline, real, copy_gbps, multi = None, None, None, None
-    if N == 1:
+    roofline, real, copy_gbps, mg = None, None, None, None
+    if not multi:
         r = bufs[0].clone() if pairs else None
         roofline, real = profile_one_sort(ctx, torch, cfg, args.config, n, gen, sort, bufs[0], r)
         del r
@@ -508,12 +533,11 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
             t1 = time.perf_counter()
-            sorter.submit(bufs[0])                      # pre-exchange pass + count exchange + the all-to-all is started
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            out_view, handle, _ = sorter._pending[0]
-            if handle is not None:
-                handle.wait()
+            sorter.submit(bufs[0])                      # pre-exchange pass + count exchange (blocks: the counts come to the host) + the all-to-all is STARTED
+            t2 = time.perf_counter()                    # (no device synchronisation here: it would wait for the exchange as well)
+            out_view, handles, _ = sorter._pending[0]
+            for h in handles or []:
+                h.wait()
             torch.cuda.synchronize()
             dist.barrier()
             t3 = time.perf_counter()
@@ -526,7 +550,7 @@ def main():
             xch_bytes = out_view.numel() * 4
         k_algo = algo_bytes_per_elem(cfg)
         sec = dt / K
-        multi = {"scheme": "fine (top 16 bits before the exchange, counting leaf over the arrived extents)" if fine else "coarse (top digit before the exchange)",
+        mg = {"scheme": "fine (top 16 bits before the exchange, counting leaf over the arrived extents)" if fine else "coarse (top digit before the exchange)",
                  "local_before_exchange_ms": round(max_over_ranks(min(pre_ms)), 3),
                  "local_after_exchange_ms": round(max_over_ranks(min(post_ms)), 3),
                  "exchange_alone_ms": round(max_over_ranks(min(xch_ms)), 3),
@@ -539,13 +563,13 @@ def main():
         roofline = {"bound": "hbm", "kernel": "whole per-GPU step (pre-exchange pass + counting leaf; exchange overlapped)",
                     "achieved": round(n * k_algo / sec / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(n * k_algo / sec / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": int(n * k_algo), "avg_launch_us": round(sec * 1e6, 1), "multi_gpu": multi}
+                    "algorithmic_bytes_per_launch": int(n * k_algo), "avg_launch_us": round(sec * 1e6, 1), "multi_gpu": mg}
 
     total = N * n * K
     value = total / dt / 1e9
     unit = "Gtuples/s" if pairs else "Gkeys/s"
     headline = "Gkeys/s + achieved HBM GB/s, 2^30 uniform u32 keys, 1/2/4/8 MI355X"
-    if N > 1:
+    if multi:
         how = (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local work; "
                + ("fine scheme: shard ordered by its top 16 bits before the exchange, one counting pass over the arrived extents after it)" if fine
                   else (f"the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N <= 4
@@ -556,17 +580,18 @@ def main():
         "metric": headline if args.config == "c2" else f"{unit} + achieved HBM GB/s, 2^{args.logn} {cfg['title']}, 1 MI355X",
         "value": round(value, 3), "unit": unit if args.config != "c2" else "Gkeys/s", "n_gpus": N, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic" + (" (REHEARSAL: gloo via host memory, all ranks on one GPU)" if rehearsal else ""),
+        "vs_baseline": None, "dtype": cfg["dtype"], "data": "synthetic" + (" (REHEARSAL: one rank exchanging with itself over RCCL)" if args.one_rank_exchange else
+                                                       " (REHEARSAL: gloo via host memory, all ranks on one GPU)" if rehearsal else ""),
         "config": {"workload": f"2^{args.logn} {cfg['title']} per GPU, in-place MSD radix sort, 8-bit digits" + how,
                    "config_id": args.config, "elements_per_gpu": n, "passes": cfg["passes_note"],
-                   "verified": bool(verified), "steps_verified": steps_verified,
+                   "verified": bool(verified), "steps_verified": steps_verified, **({"verify_failures": fail_detail[:4]} if fail_detail else {}),
                    "verified_by": "msd_check_* (device) and an independent chunked torch reduction (order, sum" + (", key == rid)" if pairs else ")"),
                    "workspace_bytes": ctx.workspace_bytes},
         "whole_sort": whole_sort_block(cfg, n, dt / K, real, copy_gbps),
         "roofline": roofline,
     }
     # ---- the other single-GPU configs in the same record (default run only): headline buffers are freed first
-    if N == 1 and args.config == "c2" and not args.no_other_configs and args.logn == 30:
+    if not multi and args.config == "c2" and not args.no_other_configs and args.logn == 30:
         a = b = None
         del bufs, rids, outs, a, b
         torch.cuda.empty_cache()
@@ -580,7 +605,7 @@ def main():
     if rank == 0:
         out["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.cpu_logn, args.cpu_logn_1t)
         print(json.dumps(out), flush=True)
-    if N > 1:
+    if multi:
         dist.barrier()            # the other ranks wait for rank 0's CPU baseline
         dist.destroy_process_group()
 

@@ -17,6 +17,10 @@
  * Uniform keys only (the top bits of a key name its rank, like the reference's radix bounds (p << 58) - 1, :1555-1557);
  * skewed keys take the sampled splitters of dist.py.  The number of ranks must be a power of two <= 256.
  * All d_* pointers are device pointers on the rank's device, 16-byte aligned.
+ * Give the context a stream of its own with HIGH priority (hipStreamCreateWithPriority), or raise GPU_MAX_HW_QUEUES to 8:
+ * HIP multiplexes streams onto 4 hardware queues by default, and a compute stream that shares its queue with the stream
+ * RCCL launches on serialises the exchange with the local work (measured: DESIGN.md section 6).  No single ncclSend /
+ * ncclRecv of these entry points is larger than 512 MiB (RCCL 2.26 moves only half of a 2 GiB message, silently).
  * Return value: 0, a negative MSD_E* code (msd_radix_hip.h), or MSD_EOVERFLOW: some rank's receive buffer is too small
  * for its key range -- decided from the all-gathered send matrix BEFORE the exchange, so every rank returns it and no
  * rank is left alone in a collective; nothing has been exchanged then (the rank's own keys are partly ordered).

@@ -11,6 +11,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -23,6 +24,7 @@ namespace {
 constexpr int kFineBits = 16;                  // the fine scheme orders a shard by its top 16 bits before the exchange
 constexpr uint32_t kFineBuckets = 1u << kFineBits;
 constexpr uint64_t kFineMinKeys = 1ull << 27;  // ... when every rank holds at least this many keys
+constexpr uint64_t kMaxPieceBytes = 1ull << 29; // largest single ncclSend / ncclRecv (see all_to_all)
 
 } // namespace
 
@@ -163,10 +165,16 @@ int all_to_all(msd_shard *sh, const T *src, T *dst, const std::vector<uint64_t> 
 {
 	const ncclDataType_t ty = sizeof(T) == 4 ? ncclUint32 : ncclUint64;
 	if (!group_open) SH_NCCL(sh, ncclGroupStart());
+	// RCCL 2.26 (ROCm 7) moves only half of a single send / receive of >= 2 GiB, silently (tools/debug/a2a_big.py: measured on
+	// the GPU box, through torch.distributed and through ncclSend / ncclRecv alike): every pair's block goes in pieces of
+	// at most 512 MiB -- several sends to one peer inside a group are matched with its receives in order.
+	const uint64_t lim = kMaxPieceBytes / sizeof(T);
 	uint64_t so = 0, ro = 0;
 	for (int p = 0; p < sh->world; ++p) {
-		if (send_cnt[p]) SH_NCCL(sh, ncclSend(src + so, send_cnt[p], ty, p, sh->comm, sh->stream));
-		if (recv_cnt[p]) SH_NCCL(sh, ncclRecv(dst + ro, recv_cnt[p], ty, p, sh->comm, sh->stream));
+		for (uint64_t a = 0; a < send_cnt[p]; a += lim)
+			SH_NCCL(sh, ncclSend(src + so + a, std::min(lim, send_cnt[p] - a), ty, p, sh->comm, sh->stream));
+		for (uint64_t a = 0; a < recv_cnt[p]; a += lim)
+			SH_NCCL(sh, ncclRecv(dst + ro + a, std::min(lim, recv_cnt[p] - a), ty, p, sh->comm, sh->stream));
 		so += send_cnt[p];
 		ro += recv_cnt[p];
 	}
@@ -370,7 +378,13 @@ int msd_sort_u32_multi(int ndev, const int *devices, uint32_t **d_keys, const ui
 			msd_ctx *ctx = nullptr;
 			msd_shard *sh = nullptr;
 			hipStream_t st = nullptr;
-			int rc = hipSetDevice(devices[i]) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess ? MSD_OK : MSD_EHIP;
+			// (a high-priority stream: it gets a hardware queue of its own -- on the default stream the compute kernels and
+			// RCCL's kernels shared one queue on the GPU box and ran strictly one after the other)
+			int lo_p = 0, hi_p = 0;
+			int rc = hipSetDevice(devices[i]) == hipSuccess && hipDeviceGetStreamPriorityRange(&lo_p, &hi_p) == hipSuccess &&
+					 hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi_p) == hipSuccess
+				 ? MSD_OK
+				 : MSD_EHIP;
 			if (!rc) rc = msd_create(&ctx, devices[i], st);
 			if (!rc) rc = msd_shard_create(&sh, ctx, comms[i]);
 			if (!rc)

@@ -71,8 +71,80 @@ class HostStagedDist:
                                   input_split_sizes=input_split_sizes, group=group)
         output.copy_(o)
 
+    def all_to_all(self, outs, ins, group=None):
+        import torch
+        o = torch.empty(sum(x.numel() for x in outs), dtype=outs[0].dtype)
+        self._d.all_to_all_single(o, torch.cat([x.reshape(-1) for x in ins]).cpu(), output_split_sizes=[x.numel() for x in outs],
+                                  input_split_sizes=[x.numel() for x in ins], group=group)
+        at = 0
+        for x in outs:
+            x.copy_(o[at:at + x.numel()])
+            at += x.numel()
+
     def __getattr__(self, name):   # ReduceOp, get_world_size, ...
         return getattr(self._d, name)
+
+
+# RCCL 2.26 (the build ROCm 7 / torch 2.10 ship) moves only HALF of a single send / receive of >= 2 GiB -- silently: a
+# one-rank all_to_all_single of 2^29 int32 comes back with its second GiB untouched (tools/debug/a2a_big.py, measured on
+# the GPU box in round 3; the same through ncclSend / ncclRecv directly).  At 2^30 keys per rank a pair's block is 2 GiB at
+# 2 ranks, 1 GiB at 4, 512 MiB at 8.  Every exchange therefore goes in pieces of at most this many bytes per pair.
+A2A_MAX_BYTES = 1 << 29
+
+
+class _Splits(list):
+    """Split sizes of one rank + the largest block any PAIR of ranks exchanges (every rank must run the same number of
+    exchange rounds)."""
+    max_block = 0
+
+
+def all_to_all_v(dist, out, inp, got_l, send_l, group=None, async_op: bool = False):
+    """``out`` <- all-to-all(v) of ``inp`` with the given split sizes, in rounds of at most A2A_MAX_BYTES per pair (one
+    ``all_to_all_single`` when every block is small).  Returns the list of Work handles (``async_op``) or []."""
+    lim = A2A_MAX_BYTES // inp.element_size()
+    world = len(send_l)
+    big = max(getattr(send_l, "max_block", 0), max(list(send_l) + list(got_l) + [0]))
+    if big <= lim:
+        if async_op:
+            return [dist.all_to_all_single(out, inp, output_split_sizes=list(got_l), input_split_sizes=list(send_l), group=group, async_op=True)]
+        dist.all_to_all_single(out, inp, output_split_sizes=list(got_l), input_split_sizes=list(send_l), group=group)
+        return []
+    soff, goff, a, b = [], [], 0, 0
+    for p in range(world):
+        soff.append(a)
+        goff.append(b)
+        a += int(send_l[p])
+        b += int(got_l[p])
+    handles = []
+    for j in range((big + lim - 1) // lim):
+        ins = [inp[soff[p] + min(j * lim, int(send_l[p])):soff[p] + min((j + 1) * lim, int(send_l[p]))] for p in range(world)]
+        outs = [out[goff[p] + min(j * lim, int(got_l[p])):goff[p] + min((j + 1) * lim, int(got_l[p]))] for p in range(world)]
+        if _no_list_all_to_all(dist, group):
+            _packed_all_to_all(dist, outs, ins, group)
+        elif async_op:
+            handles.append(dist.all_to_all(outs, ins, group=group, async_op=True))
+        else:
+            dist.all_to_all(outs, ins, group=group)
+    return handles
+
+
+def _no_list_all_to_all(dist, group) -> bool:
+    """gloo (the CPU tests' backend) has all_to_all_single but not the list form RCCL has."""
+    try:
+        return str(dist.get_backend(group)) == "gloo" and not isinstance(dist, HostStagedDist)
+    except Exception:
+        return False
+
+
+def _packed_all_to_all(dist, outs, ins, group):
+    import torch
+    o = torch.empty(sum(x.numel() for x in outs), dtype=outs[0].dtype, device=outs[0].device)
+    dist.all_to_all_single(o, torch.cat([x.reshape(-1) for x in ins]), output_split_sizes=[x.numel() for x in outs],
+                           input_split_sizes=[x.numel() for x in ins], group=group)
+    at = 0
+    for x in outs:
+        x.copy_(o[at:at + x.numel()])
+        at += x.numel()
 
 
 def _log2(g: int) -> int:
@@ -102,7 +174,9 @@ def exchange_counts(dist, send, capacity: int, world: int, group=None):
                               ", ".join(f"{r}: {t} keys for capacity {c}" for r, t, c in over) +
                               " (raise the slack -- the reference's fudge -- or use sort_sharded_u32_sampled)")
     me = _rank(dist, group)
-    return mat[me, :world].tolist(), mat[:, me].tolist()
+    send_l = _Splits(mat[me, :world].tolist())
+    send_l.max_block = int(mat[:, :world].max())
+    return send_l, mat[:, me].tolist()
 
 
 def exchange_bucket_counts(dist, counts, capacity: int, world: int, group=None):
@@ -123,7 +197,9 @@ def exchange_bucket_counts(dist, counts, capacity: int, world: int, group=None):
                               ", ".join(f"{r}: {t} keys for capacity {c}" for r, t, c in over) +
                               " (raise the slack -- the reference's fudge -- or use sort_sharded_u32_sampled)")
     me = _rank(dist, group)
-    return to_rank[me].tolist(), to_rank[:, me].tolist(), mat[:, me * per:(me + 1) * per].tolist()
+    send_l = _Splits(to_rank[me].tolist())
+    send_l.max_block = int(to_rank.max())
+    return send_l, to_rank[:, me].tolist(), mat[:, me * per:(me + 1) * per].tolist()
 
 
 FINE_BITS = 16          # the fine scheme orders a shard by its top 16 bits before the exchange ...
@@ -165,7 +241,9 @@ def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
                               " (raise the slack -- the reference's fudge -- or use sort_sharded_u32_sampled)")
     me = _rank(dist, group)
     mine = allc[:, me * nbl:(me + 1) * nbl].contiguous()
-    return to_rank_h[me].tolist(), to_rank_h[:, me].tolist(), mine
+    send_l = _Splits(to_rank_h[me].tolist())
+    send_l.max_block = int(to_rank_h.max())
+    return send_l, to_rank_h[:, me].tolist(), mine
 
 
 def _fine_counts(engine, keys):
@@ -228,19 +306,19 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
     if use_fine(keys.numel(), world, work is not None, scheme, _force_exchange):
         send_l, got_l, mine = exchange_fine_counts(dist, _fine_counts(engine, keys), min(recv.numel(), work.numel()), world, group)
         m = int(sum(got_l))
-        dist.all_to_all_single(recv[:m], keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+        all_to_all_v(dist, recv[:m], keys, got_l, send_l, group)
         return _fine_finish(engine, recv, work, mine, got_l, _rank(dist, group), world)
     counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
     if work is None or world > 4:                                # (8 ranks and more: see ShardedSorter)
         send = counts.view(world, 256 // world).sum(dim=1)       # keys per destination rank
         send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
         out = recv[:int(sum(got_l))]
-        dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+        all_to_all_v(dist, out, keys, got_l, send_l, group)
         engine.sort_u32(out, end_bit=32 - lg)
         return out
     send_l, got_l, mine = exchange_bucket_counts(dist, counts, min(recv.numel(), work.numel()), world, group)
     m = int(sum(got_l))
-    dist.all_to_all_single(recv[:m], keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    all_to_all_v(dist, recv[:m], keys, got_l, send_l, group)
     return _gather_and_sort(engine, recv[:m], work[:m], mine)
 
 
@@ -262,7 +340,7 @@ def sort_sharded_u64(engine, keys, recv, dist, world: int, group=None):
     send = counts.view(world, 256 // world).sum(dim=1)
     send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)
     out = recv[:int(sum(got_l))]
-    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    all_to_all_v(dist, out, keys, got_l, send_l, group)
     engine.sort_u64(out, end_bit=64 - lg)
     return out
 
@@ -286,8 +364,8 @@ def sort_sharded_pairs_u64(engine, keys, rids, recv_keys, recv_rids, dist, world
     send_l, got_l = exchange_counts(dist, send, recv_keys.numel(), world, group)
     m = int(sum(got_l))
     out_k, out_r = recv_keys[:m], recv_rids[:m]
-    dist.all_to_all_single(out_k, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
-    dist.all_to_all_single(out_r, rids, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    all_to_all_v(dist, out_k, keys, got_l, send_l, group)
+    all_to_all_v(dist, out_r, rids, got_l, send_l, group)
     engine.sort_pairs_u64(out_k, out_r, end_bit=64 - lg)
     return out_k, out_r
 
@@ -327,7 +405,7 @@ class ShardedSorter:
         self._async = None
 
     def _all_to_all(self, out, keys, got_l, send_l):
-        # torch.distributed returns a Work whose wait() orders the current stream after the exchange; stand-ins without
+        # torch.distributed returns Work handles whose wait() orders the current stream after the exchange; stand-ins without
         # ``async_op`` (HostStagedDist, tests) exchange synchronously.  Decided once from the signature -- a TypeError
         # raised by the real backend (bad split list, dtype) is an error, not a reason to run the collective again.
         if self._async is None:
@@ -336,11 +414,7 @@ class ShardedSorter:
                 self._async = "async_op" in inspect.signature(self.dist.all_to_all_single).parameters
             except (TypeError, ValueError):
                 self._async = False
-        if self._async:
-            return self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l,
-                                               group=self.group, async_op=True)
-        self.dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=self.group)
-        return None
+        return all_to_all_v(self.dist, out, keys, got_l, send_l, self.group, async_op=self._async)
 
     def submit(self, keys) -> None:
         if self.world == 1 and not self._force:
@@ -369,9 +443,9 @@ class ShardedSorter:
         self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), mine))
 
     def collect(self):
-        out, handle, mine = self._pending.pop(0)
-        if handle is not None:
-            handle.wait()
+        out, handles, mine = self._pending.pop(0)
+        for h in handles or []:
+            h.wait()
         if isinstance(mine, tuple):   # fine scheme: the counting leaf reads the extents in the receive buffer, writes a work buffer
             _, recv, counts, got_l = mine
             final = self.fine_work[self._wslot]
@@ -432,11 +506,11 @@ def _sort_sharded_sampled(engine, keys, rids, recv, recv_rids, dist, world: int,
     send_l, got_l = exchange_counts(dist, send, recv.numel(), world, group)   # int64[world]: range sizes, ranges contiguous
     m_out = int(sum(got_l))
     out = recv[:m_out]
-    dist.all_to_all_single(out, keys, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+    all_to_all_v(dist, out, keys, got_l, send_l, group)
     out_r = None
     if pairs:
         out_r = recv_rids[:m_out]
-        dist.all_to_all_single(out_r, rids, output_split_sizes=got_l, input_split_sizes=send_l, group=group)
+        all_to_all_v(dist, out_r, rids, got_l, send_l, group)
     local_sort(out, out_r)
     return (out, out_r) if pairs else out
 

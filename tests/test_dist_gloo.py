@@ -126,10 +126,13 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, kind, q, sampled=False):
+def _worker(rank, world, port, n, kind, q, sampled=False, piece_bytes=0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if piece_bytes:   # exchanges in several rounds of small pieces (the product's limit is 512 MiB per pair and round)
+        import inplacemsdradixsort_amd.dist as D
+        D.A2A_MAX_BYTES = piece_bytes
     from inplacemsdradixsort_amd.dist import sort_sharded_u32, sort_sharded_u32_sampled
     from oracle import oracle as O
     if kind == "uniform":
@@ -174,6 +177,60 @@ def test_sharded_sort_over_gloo(world, kind, work):
         if res[r].size:
             lg = world.bit_length() - 1
             assert ((res[r] >> np.uint32(32 - lg)) == r).all()
+
+
+@pytest.mark.parametrize("world,kind,how,piece_bytes", [(2, "uniform", False, 4096), (4, "zipf", "fine", 1000), (2, "zipf", "work", 20000),
+                                                        (4, "zipf", True, 512), (8, "uniform", "fine", 400)])
+def test_exchange_in_pieces_over_gloo(world, kind, how, piece_bytes):
+    """The all-to-all in rounds of bounded pieces (RCCL 2.26 moves only half of a >= 2 GiB message): ragged blocks, blocks
+    smaller than a piece, piece sizes that do not divide the blocks, every scheme."""
+    n = 20000 if world < 8 else 6000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, kind, q, how, piece_bytes)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    gen = O.gen_uniform_u32 if kind == "uniform" else O.gen_zipf_u32
+    allk = np.concatenate([gen(n, first=r * n) for r in range(world)])
+    assert (np.concatenate([res[r] for r in range(world)]) == O.sort_u32(allk)).all()
+
+
+def test_all_to_all_v_rounds_match_one_call():
+    """all_to_all_v's slicing, alone: one rank, a recording stand-in for torch.distributed."""
+    import inplacemsdradixsort_amd.dist as D
+
+    class Rec:
+        calls = 0
+
+        def all_to_all(self, outs, ins, group=None, async_op=False):
+            Rec.calls += 1
+            assert all(o.numel() == i.numel() and i.numel() * i.element_size() <= D.A2A_MAX_BYTES for o, i in zip(outs, ins))
+            for o, i in zip(outs, ins):
+                o.copy_(i)
+            return "h"
+
+        def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+            Rec.calls += 1
+            out[:sum(output_split_sizes)].copy_(inp[:sum(input_split_sizes)])
+            return "h"
+
+    old = D.A2A_MAX_BYTES
+    try:
+        inp = torch.arange(1000, dtype=torch.int32)
+        for lim_b, want_calls in ((1 << 29, 1), (400, 10), (4000, 1), (396, 11)):
+            D.A2A_MAX_BYTES, Rec.calls = lim_b, 0
+            out = torch.full((1200,), -1, dtype=torch.int32)
+            h = D.all_to_all_v(Rec(), out, inp, [1000], D._Splits([1000]), async_op=True)
+            assert Rec.calls == want_calls and len(h) == want_calls
+            assert (out[:1000] == inp).all() and (out[1000:] == -1).all()
+    finally:
+        D.A2A_MAX_BYTES = old
 
 
 def _pipeline_worker(rank, world, port, n, shards, q, scheme=None):
