@@ -261,7 +261,7 @@ class MsdContext:
         out = {}
         for name in ("rounds", "parents", "stripes", "children", "slots", "holes", "chain_steps",
                      "small_segments", "count_segments", "big_count_segments", "direct_rounds", "regpart_rounds", "skipped_bits", "bit_skip_restarts", "bit_skip_checked_by_histogram",
-                     "merge_rejected", "leaf17_segments", "leaf17_rejected", "workspace_bytes"):
+                     "merge_rejected", "leaf17_segments", "leaf17_rejected", "leaf17_slow_segments", "leaf17_launches", "workspace_bytes"):
             v = C.c_uint64()
             if self._L.msd_stat(self._h, name.encode(), C.byref(v)) == 0:
                 out[name] = int(v.value)

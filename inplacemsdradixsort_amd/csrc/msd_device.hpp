@@ -119,7 +119,7 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t nhot;           // per round: lists with sharded claim cursors (chains_kernel)
 	uint32_t nslow2;         // counting-leaf segments merge_count_kernel (list mode) left to count_walk_kernel
 	uint32_t count_ticket4;  // work ticket of merge_count_kernel (list mode)
-	uint32_t pad_;
+	uint32_t l17_slow;       // leaf17_kernel: segments whose groups took the position-by-position fix-up
 };
 static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used for 64-bit atomics");
 
@@ -1951,8 +1951,10 @@ template <typename K, typename V> struct LeafCountLds {
 template <typename K, typename V>
 __global__ __launch_bounds__((Cfg<K, V>::SORT_TH)) void leaf_count_sort_kernel(K *__restrict__ keys,
 	uint64_t *__restrict__ vals, const Segment *__restrict__ segs, uint32_t nsegs,
-	Segment *__restrict__ fallback, Counters *__restrict__ ctr, uint32_t *__restrict__ ticket)
+	Segment *__restrict__ fallback, Counters *__restrict__ ctr, uint32_t *__restrict__ ticket,
+	const uint32_t *__restrict__ nsegs_dev = nullptr)
 {
+	if (nsegs_dev) nsegs = *nsegs_dev; // (the list was written by the launch before this one)
 	// Persistent workgroups (one per CU fits the LDS): segments by ticket; the next segment's elements are
 	// loaded (branch-free) as soon as the current ones have left the registers for LDS, so its load
 	// latency is hidden behind the fix-up and the write-back of the current one.

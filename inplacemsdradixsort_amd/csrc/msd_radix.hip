@@ -55,7 +55,7 @@ struct msd_ctx {
 	uint64_t direct_min_parent = 1ull << 17; // rounds after the first: smallest parent
 	int regpart = 1;       // u64 keys / tuples: rounds of small parents as one register-resident pass (0: A/B comparisons)
 	int count16 = 1;       // u32 keys: count_place16_kernel in front of count_place_kernel (0: A/B comparisons)
-	int leaf17 = 1;        // tuples: segments of <= 17408 tuples are finished by leaf17_kernel (0: register partition + small leaves; A/B comparisons)
+	int leaf17 = 1;        // u64 keys and tuples: segments of <= 17408 elements are finished by leaf17_kernel (0: tuples: register partition + small leaves, keys: leaf_count_sort_kernel; A/B comparisons)
 	int stream_kernel = 2; // streaming classify: 2 = classify_stream2_kernel (lean tile loop), 1 = classify_kernel (round 2; A/B comparisons)
 	int mid_leaf = 1;      // u32 keys: merge_count_kernel (list mode) in front of count_walk_kernel (0: A/B comparisons)
 	int merge_leaf = 0;    // msd_merge_buckets_u32: 0 = by bucket size, 1 = merge_place16_kernel, 2 = merge_count_kernel (tests)
@@ -681,9 +681,10 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 							HIPCHK(c, hipMemcpyAsync(d_segs, c->pinned, (size_t)np * sizeof(Segment), hipMemcpyHostToDevice, c->stream));
 						}
 						HIPCHK(c, hipMemsetAsync(&ctr->nslow2, 0, sizeof(uint32_t), c->stream));
+						HIPCHK(c, hipMemsetAsync(&ctr->l17_slow, 0, sizeof(uint32_t), c->stream));
 						phase_mark(c, "plan+upload");
 						hipLaunchKernelGGL((leaf17_kernel<V>), dim3(std::min<uint32_t>(np, (uint32_t)c->sm_count)), dim3(kL17Th), kL17Lds, c->stream,
-								   (uint64_t *)keys, vals, (const Segment *)d_segs, np, d_rej, &ctr->nslow2, ctr);
+								   (uint64_t *)keys, vals, (const Segment *)d_segs, np, d_rej, &ctr->nslow2, ctr, 0u);
 						HIPCHK(c, hipGetLastError());
 						phase_mark(c, "leaf17");
 						Counters hc;
@@ -692,6 +693,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 						memcpy(&hc, c->pinned, sizeof hc);
 						if (hc.errors) return fail(c, MSD_EINTERNAL, "leaf17: %u internal invariant violations", hc.errors);
 						add_stat(c, "leaf17_segments", np - hc.nslow2);
+						add_stat(c, "leaf17_slow_segments", hc.l17_slow);
 						cur = rest;
 						if (hc.nslow2) { // rejected segments: the register partition + the small leaves finish them
 							rc = pinned_reserve(c, (size_t)hc.nslow2 * sizeof(Segment));
@@ -1187,7 +1189,27 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		// persistent workgroups with prefetch of the next segment: as many per CU as the LDS holds
 		constexpr size_t leaf_lds = LeafCountLds<K, V>::bytes;
 		const uint32_t leaf_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048 / C::SORT_TH, (160 * 1024) / (leaf_lds + 512)));
-		if (nsmall_host) {
+		bool small_done = false;
+		if constexpr (!HV && sizeof(K) == 8) {
+			// u64 keys, segments of about 2^14 (what two 8-bit rounds leave of 2^30 keys): leaf17_kernel -- counters for up to
+			// 16 bits where the staging buffer will be, one lane per group of equal counted bits -- finishes a segment in 0.6
+			// of this leaf's time; what it leaves (segments shorter than 4096 keys, a group of more than 48) goes on to it.
+			if (c->leaf17 && nsmall_host && n / nsmall_host >= 8192) {
+				int rc = slab_reserve(c, (size_t)nsmall_host * sizeof(Segment) + 4096);
+				if (rc) return rc;
+				Segment *d_rej = reinterpret_cast<Segment *>(c->slab);
+				HIPCHK(c, hipMemsetAsync(&ctr->nslow2, 0, sizeof(uint32_t), c->stream));
+				HIPCHK(c, hipMemsetAsync(&ctr->l17_slow, 0, sizeof(uint32_t), c->stream));
+				hipLaunchKernelGGL((leaf17_kernel<NoVal>), dim3(std::min<uint32_t>(nsmall_host, (uint32_t)c->sm_count)), dim3(kL17Th), kL17Lds, c->stream,
+						   (uint64_t *)keys, (uint64_t *)nullptr, (const Segment *)small, nsmall_host, d_rej, &ctr->nslow2, ctr, 4096u);
+				hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(nsmall_host, (uint32_t)c->sm_count * leaf_per_cu)), dim3(C::SORT_TH), leaf_lds, c->stream,
+						   keys, vals, (const Segment *)d_rej, nsmall_host, small + nsmall_host, ctr, &ctr->leaf_ticket[0], (const uint32_t *)&ctr->nslow2);
+				HIPCHK(c, hipGetLastError());
+				add_stat(c, "leaf17_launches", 1);
+				small_done = true;
+			}
+		}
+		if (nsmall_host && !small_done) {
 			hipLaunchKernelGGL((leaf_count_sort_kernel<K, V>), dim3(std::min<uint32_t>(nsmall_host, (uint32_t)c->sm_count * leaf_per_cu)), dim3(C::SORT_TH), leaf_lds, c->stream,
 					   keys, vals, small, nsmall_host, small + nsmall_host, ctr, &ctr->leaf_ticket[0]);
 			HIPCHK(c, hipGetLastError());
@@ -1235,9 +1257,8 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 	if constexpr (sizeof(K) == 8) {
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&regpart_kernel<V>),
 					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRpLds));
-		if constexpr (has_val<V>::value)
-			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf17_kernel<V>),
-						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL17Lds));
+		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf17_kernel<V>),
+					      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kL17Lds));
 	}
 	HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&leaf_count_sort_kernel<K, V>),
 				      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LeafCountLds<K, V>::bytes));

@@ -100,7 +100,27 @@ def test_leaf17_duplicates_and_rejected_segments(ctx):
     out, rid = host(tk), tr.cpu().numpy()
     assert (out == np.sort(k)).all() and (k[rid] == out).all() and (np.sort(rid) == np.arange(n)).all()
     st = ctx.stats()
-    assert st.get("leaf17_segments", 0) >= 1 and st.get("leaf17_rejected", 0) >= 1, st
+    assert st.get("leaf17_segments", 0) >= 1 and st.get("leaf17_rejected", 0) >= 1 and st.get("leaf17_slow_segments", 0) >= 1, st
+
+
+def test_leaf17_long_groups_and_many_groups(ctx):
+    """leaf17_kernel's position-by-position fix-up (the fallback of the one-lane-per-group fix-up): a segment whose groups
+    of equal counted bits have 7..48 members, and a segment with more groups of two or more than the group list holds."""
+    import torch
+    rng = np.random.default_rng(78)
+    n = 4_000_001
+    k = rng.integers(0, 1 << 64, n, dtype=np.uint64)                # (256 first-round buckets of about 15.6 Ki tuples)
+    low = np.uint64((1 << 20) - 1)
+    for bucket, distinct in ((10, 1024), (11, 8192)):               # about 15 tuples per counted value; about 4600 groups >= 2
+        sel = (k >> np.uint64(56)) == np.uint64(bucket)
+        c = (k[sel] >> np.uint64(20)) % np.uint64(distinct)
+        k[sel] = (np.uint64(bucket) << np.uint64(56)) | (c << np.uint64(30)) | (k[sel] & low)
+    tk, tr = dev(k), torch.arange(n, dtype=torch.int64, device="cuda")
+    ctx.sort_pairs_u64(tk, tr)
+    out, rid = host(tk), tr.cpu().numpy()
+    assert (out == np.sort(k)).all() and (k[rid] == out).all() and (np.sort(rid) == np.arange(n)).all()
+    st = ctx.stats()
+    assert st.get("leaf17_segments", 0) >= 256 and st.get("leaf17_slow_segments", 0) >= 2 and st.get("leaf17_rejected", 0) == 0, st
 
 
 @pytest.mark.parametrize("regpart", [0, 1])
@@ -110,6 +130,36 @@ def test_regpart_modes_u64_keys(ctx, regpart):
     t = dev(k)
     ctx.sort_u64(t)
     assert (host(t) == np.sort(k)).all()
+
+
+@pytest.mark.parametrize("leaf17", [0, 1])
+@pytest.mark.parametrize("kind", ["uniform", "dups", "groups", "short"])
+def test_leaf17_u64_keys(ctx, leaf17, kind):
+    """u64 keys: the segments two rounds leave (about 2^14 keys) are finished by leaf17_kernel<NoVal>; what it does not take
+    (short segments, groups of more than 48 keys equal on the counted bits) goes on to leaf_count_sort_kernel."""
+    rng = np.random.default_rng(79)
+    n = 4_000_001
+    k = rng.integers(0, 1 << 64, n, dtype=np.uint64)
+    if kind == "dups":
+        k[5::5] = k[4::5][: k[5::5].size]
+    elif kind == "groups":   # bucket 10: about 15 keys per counted value; bucket 11: more groups than the list holds; bucket 12: rejected
+        low = np.uint64((1 << 20) - 1)
+        for bucket, distinct in ((10, 1024), (11, 8192), (12, 8)):
+            sel = (k >> np.uint64(56)) == np.uint64(bucket)
+            c = (k[sel] >> np.uint64(20)) % np.uint64(distinct)
+            k[sel] = (np.uint64(bucket) << np.uint64(56)) | (c << np.uint64(30)) | (k[sel] & low)
+    elif kind == "short":    # half of the first-round buckets are split once more into segments of a few hundred keys
+        sel = ((k >> np.uint64(56)) & np.uint64(1)) == np.uint64(1)
+        k[sel] &= ~(np.uint64(0xFFFF) << np.uint64(32))
+    ctx.set_option("leaf17", leaf17)
+    try:
+        t = dev(k)
+        ctx.sort_u64(t)
+    finally:
+        ctx.set_option("leaf17", 1)
+    assert (host(t) == np.sort(k)).all()
+    st = ctx.stats()
+    assert st.get("leaf17_launches", 0) == (1 if leaf17 else 0), st
 
 
 def test_last_error_of_the_reference_api_is_empty_after_a_good_sort():
