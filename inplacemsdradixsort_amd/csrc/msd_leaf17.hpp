@@ -31,6 +31,9 @@ constexpr uint32_t kL17Cap = kL17Th * (kL17Vec * 2 + 1);              // 17408 e
 #define MSD_L17_BITS 16
 #define MSD_L17_WIN 2
 #endif
+#ifndef MSD_L17_PREFETCH // (0: every segment's keys are requested when its turn comes; A/B comparisons)
+#define MSD_L17_PREFETCH 1
+#endif
 constexpr int kL17BitsMin = 13, kL17BitsMax = MSD_L17_BITS;          // counted bits: ceil(log2 n) + 2 within these bounds
 constexpr size_t kL17Side = kL17Cap;                                 // a byte per position (the distances of the fix-up)
 // The 16-bit counters (two per word) lie where the staging buffer and the distances will be -- the keys wait in registers
@@ -63,8 +66,36 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 	const uint32_t tid0 = threadIdx.x;
 	auto rfl = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
 
-	// (Prefetching the next segment's keys behind the keys' write-back was tried: carried across the loop through its three
-	// early ways out the key registers become conditionally written loop-carried values -- 266 spilled registers.)
+	// The keys of a workgroup's NEXT segment are requested as soon as the current ones have left their registers for the
+	// staging buffer.  Measured (2^30 u64 keys / tuples, -DMSD_L17_PREFETCH=0 against 1 on one box): no difference -- the
+	// 7 thousand cycles the keys' arrival loses reappear where the loads are issued.  With every CU at it a workgroup's share
+	// of the memory bandwidth is about 9 bytes per cycle: 139 KiB take 15 thousand cycles to arrive and as long to leave
+	// whenever they are requested, which is all of the tuple leaf's 60 thousand cycles per segment (5.3 TB/s) and 31 of the
+	// key leaf's 45.  Hiding the rest needs the loads in flight during the counting phases, i.e. a second set of key
+	// registers: tried (= 2), the compiler parks exactly those 34 registers in scratch memory.
+	// (segment sj's keys: vector v of thread t = grid elements (v * TH + t) * 2, + 1; tail element NV * TH * 2 + t; lanes beyond
+	// the segment read its last vector again; behind the list's end the last segment is read once more, unused)
+	uint64_t k[kL17Vec * 2 + 1];
+	auto load_keys = [&](uint64_t(&k)[kL17Vec * 2 + 1], uint32_t sj) {
+		uint32_t tl = tid0;
+		asm volatile("" : "+v"(tl));
+		const Segment g2 = segs[min(sj, nsegs - 1u)];
+		const uint64_t start2 = (uint64_t)rfl((uint32_t)g2.start) | ((uint64_t)rfl((uint32_t)(g2.start >> 32)) << 32);
+		const uint32_t off2 = (uint32_t)(start2 & 1u);
+		const uint32_t tot2 = max(rfl((uint32_t)g2.count) + off2, 1u);
+		const uint64_t *kb2 = keys + (start2 - off2);
+		const uint32_t lastv2 = (tot2 - 1u) >> 1;
+#pragma unroll
+		for (int v = 0; v < kL17Vec; ++v) {
+			const uint32_t q = min((uint32_t)(v * kL17Th) + tl, lastv2) * 2u;
+			const u32x4 a = *reinterpret_cast<const u32x4 *>(kb2 + q);
+			k[2 * v] = (uint64_t)a.x | ((uint64_t)a.y << 32);
+			k[2 * v + 1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
+		}
+		k[kL17Vec * 2] = kb2[min((uint32_t)(kL17Vec * kL17Th * 2) + tl, tot2 - 1u)];
+	};
+	constexpr bool kAhead = MSD_L17_PREFETCH != 0;
+	if (kAhead && blockIdx.x < nsegs) load_keys(k, blockIdx.x);
 	MSD_STAMP_DECL(9);
 	MSD_STAMP_START();
 	for (uint32_t si = blockIdx.x; si < nsegs; si += gridDim.x) {
@@ -84,21 +115,13 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 			// too long for the staging buffer (with its first element on an odd index), or shorter than this kernel is worth:
 			// left, untouched, to whoever takes the rejected segments (fewer than two elements or no open bit: nothing to do)
 			if (tid == 0 && cnt64 >= 2 && bits != 0 && bits <= 64) rejected[atomicAdd(nrejected, 1u)] = g;
+			if constexpr (MSD_L17_PREFETCH == 1) load_keys(k, si + gridDim.x);
 			continue;
 		}
 		const uint32_t n = (uint32_t)cnt64, tot = n + off; // the segment on the 16-byte grid: elements [off, tot)
 		uint64_t *kb = keys + (start - off), *vb = HV ? vals + (start - off) : nullptr;
-		// ---- read: vector v of thread t = grid elements (v * TH + t) * 2, + 1; tail element NV * TH * 2 + t
-		uint64_t k[NK];
 		const uint32_t lastv = (tot - 1u) >> 1;
-#pragma unroll
-		for (int v = 0; v < NV; ++v) {
-			const uint32_t q = min((uint32_t)(v * TH) + tid, lastv) * 2u; // (beyond the segment: its last vector again, ignored)
-			const u32x4 a = *reinterpret_cast<const u32x4 *>(kb + q);
-			k[2 * v] = (uint64_t)a.x | ((uint64_t)a.y << 32);
-			k[2 * v + 1] = (uint64_t)a.z | ((uint64_t)a.w << 32);
-		}
-		k[NK - 1] = kb[min((uint32_t)(NV * TH * 2) + tid, tot - 1u)];
+		if constexpr (!kAhead) load_keys(k, si);
 		auto elem = [&](int u) -> uint32_t { return u < NV * 2 ? (uint32_t)((u / 2) * TH * 2) + tid * 2 + (u % 2) : (uint32_t)(NV * TH * 2) + tid; };
 		(void)elem;
 		// ---- which bits vary (OR / AND over the segment), counters cleared
@@ -140,6 +163,7 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 		const uint64_t vopen = (s_or[0] ^ s_or[1]) & openmask;
 		if (vopen == 0) { // (uniform) constant on the open bits: already sorted
 			__syncthreads();
+			if constexpr (MSD_L17_PREFETCH == 1) load_keys(k, si + gridDim.x);
 			continue;
 		}
 		const uint32_t nbits = (uint32_t)(64 - __builtin_clzll((unsigned long long)vopen));
@@ -226,13 +250,13 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 			*o = k[u];
 			if (u % 6 == 5) __builtin_amdgcn_sched_barrier(0);
 		}
+		if constexpr (MSD_L17_PREFETCH == 1) load_keys(k, si + gridDim.x); // (the key registers are free from here on)
 		if (HV && groups) { // the distances start at zero
 			const u32x4 zero = { 0u, 0u, 0u, 0u };
 			for (uint32_t j = tid * 16u; j < (uint32_t)kL17Side; j += TH * 16u) *reinterpret_cast<u32x4 *>(dl + j) = zero;
 		}
 		__syncthreads();
 		MSD_STAMP(3); // keys into LDS
-		bool replace = false; // the keys have to be placed again from their registers (the slow fix-up only)
 		if (groups) { // (uniform)
 			// (same group <=> the keys agree above `shift` <=> their XOR is below 2^shift: one 64-bit compare against a uniform
 			// bound instead of two 64-bit shifts, which run at a quarter of the rate)
@@ -349,13 +373,20 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 					dl[idx] = (int8_t)((int)before - (int)left);
 				}
 				__syncthreads();
+				// (the elements' owners take their keys back from the staging buffer: the key registers hold the next segment's)
+				uint64_t kk[NK];
 #pragma unroll
 				for (int u = 0; u < NK; ++u) {
 					const uint32_t idx = (pr[u] >> 31) ? 0u : (pr[u] & 0x7FFFFFFFu);
+					kk[u] = sg[idx];
 					pr[u] = (pr[u] & 0x80000000u) | (uint32_t)((int)idx + (int)dl[idx]);
 				}
 				__syncthreads(); // every look-up is done: the staging buffer is free
-				replace = true;
+#pragma unroll
+				for (int u = 0; u < NK; ++u) {
+					uint64_t *o = (pr[u] >> 31) ? junk + lane : stage + (pr[u] & 0x7FFFFFFFu) + off;
+					*o = kk[u];
+				}
 			}
 		}
 		// ---- keys, then payloads: to their final places in the staging buffer (on the array's 16-byte grid), out as whole vectors
@@ -387,8 +418,7 @@ __global__ __launch_bounds__(kL17Th, 4) void leaf17_kernel(uint64_t *__restrict_
 			}
 		};
 		MSD_STAMP(5); // fix-up
-		// (the keys already lie at their final places in the staging buffer unless the slow fix-up ran)
-		if (replace) place(k);
+		// (the keys lie at their final places in the staging buffer)
 		// The payloads start travelling once the keys have left their registers, i.e. while the keys are stored.  (Loaded
 		// earlier -- before the fix-up, or before the keys' last LDS write -- they are live together with the 34 key
 		// registers: the compiler parks registers in scratch memory, which profiles/pmc_traffic_c5a.json showed as 13 GB of

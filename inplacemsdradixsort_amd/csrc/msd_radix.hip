@@ -642,7 +642,6 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 		return MSD_OK;
 	};
 	bool leaf17_ok = true; // (tuples) leaf17_kernel has rejected nothing yet in this call
-	uint32_t dev_bits_min = 0; // fewest open bits among the segments of dev_list
 	bool again = true;
 	while (again) {
 	again = false;
@@ -661,11 +660,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					// registers and LDS, written once) instead of a register partition + the small leaves; what it rejects
 					// (a group of > 48 tuples equal on the counted bits) takes that way.  A leaf must not run behind an
 					// unconfirmed leading-bit skip.
-					// (segments with <= 16 open bits -- tuples whose upper key half is constant, config 5b -- stay with the register
-					// partition: its children have <= 13 open bits, which the small leaf counts in one go without any fix-up)
-					bool wide = dev_np ? dev_bits_min > 16u : !fit.empty();
-					for (auto &sg : fit) wide = wide && sg.bits > 16u;
-					if (c->leaf17 && leaf17_ok && !unverified && wide && (dev_np || fit.size() >= 64 || (!fit.empty() && rest.empty()))) {
+					// (segments with <= 16 open bits -- tuples whose upper key half is constant, config 5b -- too: the leaf counts up to
+					// 16 bits, such a segment has no groups to put in order at all)
+					if (c->leaf17 && leaf17_ok && !unverified && (dev_np || fit.size() >= 64 || (!fit.empty() && rest.empty()))) {
 						const bool on_device = dev_np != 0;
 						const uint32_t np = on_device ? dev_np : (uint32_t)fit.size();
 						dev_np = 0;
@@ -1028,8 +1025,6 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			if (c->regpart && hc.next_parents >= 64 && (uint64_t)hc.next_max + 1 <= kRpCap) {
 				HIPCHK(c, hipMemcpyAsync(dev_list, rb.next_parents, (size_t)hc.next_parents * sizeof(Segment), hipMemcpyDeviceToDevice, c->stream));
 				dev_np = hc.next_parents;
-				dev_bits_min = 64;
-				for (size_t i = 0; i < np; ++i) dev_bits_min = std::min(dev_bits_min, rp.parents[i].shift);
 				stays_on_device = true;
 			}
 		}
