@@ -399,7 +399,7 @@ def main():
         gen(t, s)
         bufs.append(t)
         rids.append(t.clone() if pairs else None)   # rid = key, the reference's check(..., same=1) convention (src/msb_64.c:2461)
-    ctx.reserve(n + n // 8, cfg["key"], cfg["val"])
+    ctx.reserve(n + n // 8 if multi else n, cfg["key"], cfg["val"])   # (N > 1: a rank may receive up to n / 8 more than it sent)
     checks0 = [ctx.check(t) for t in bufs]          # (violations, sum, xor) of every input
     # N > 1: receive buffers with 12.5 % slack (the reference's fudge); the exchange of step s runs (RCCL stream, xGMI)
     # while step s-1 is finished locally -- inplacemsdradixsort_amd.dist.ShardedSorter.

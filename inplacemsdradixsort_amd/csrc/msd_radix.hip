@@ -103,7 +103,9 @@ static void add_stat(msd_ctx *c, const char *name, uint64_t v)
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static int dev_reserve(msd_ctx *c, char *&p, size_t &have, size_t bytes)
+// (exact: msd_reserve's sizes are the planner's own worst case for the shape; a buffer that has to grow in the middle of a
+// sort gets an eighth on top, so that the next slightly bigger round does not allocate again)
+static int dev_reserve(msd_ctx *c, char *&p, size_t &have, size_t bytes, bool exact = false)
 {
 	if (bytes <= have) return MSD_OK;
 	if (p) {
@@ -112,21 +114,21 @@ static int dev_reserve(msd_ctx *c, char *&p, size_t &have, size_t bytes)
 		p = nullptr;
 		have = 0;
 	}
-	bytes = align_up(bytes + bytes / 8, 1 << 20);
+	bytes = align_up(exact ? bytes : bytes + bytes / 8, 1 << 20);
 	hipError_t e = hipMalloc((void **)&p, bytes);
 	if (e != hipSuccess) return fail(c, MSD_ENOMEM, "workspace hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
 	have = bytes;
 	return MSD_OK;
 }
-static int slab_reserve(msd_ctx *c, size_t bytes) { return dev_reserve(c, c->slab, c->slab_bytes, bytes); }
-static int keep_reserve(msd_ctx *c, size_t bytes) { return dev_reserve(c, c->keep, c->keep_bytes, bytes); }
+static int slab_reserve(msd_ctx *c, size_t bytes, bool exact = false) { return dev_reserve(c, c->slab, c->slab_bytes, bytes, exact); }
+static int keep_reserve(msd_ctx *c, size_t bytes, bool exact = false) { return dev_reserve(c, c->keep, c->keep_bytes, bytes, exact); }
 
 // Leaf lists grow between rounds (the host knows how many children a round can add);
 // live entries are carried over.
-static int lists_reserve(msd_ctx *c, size_t need, size_t live_general, size_t live_count)
+static int lists_reserve(msd_ctx *c, size_t need, size_t live_general, size_t live_count, bool exact = false)
 {
 	if (need <= c->lists_cap) return MSD_OK;
-	const size_t cap = align_up(need + need / 2, 4096);
+	const size_t cap = align_up(exact ? need : need + need / 2, 4096);
 	Segment *nb = nullptr;
 	hipError_t e = hipMalloc((void **)&nb, 4 * cap * sizeof(Segment));
 	if (e != hipSuccess) return fail(c, MSD_ENOMEM, "leaf list hipMalloc failed: %s", hipGetErrorString(e));
@@ -395,11 +397,13 @@ static int run_scan(msd_ctx *c, const uint64_t *in, uint64_t *out, uint64_t n,
 
 // ------------------------------------------------------------------ the sort
 
+// Leaf-list entries msd_reserve() provides up front: what evenly spread keys need (two 8-bit rounds over 2^30 u32 keys
+// leave 2^16 counting segments; a round reserves room for one entry per child on top of the live ones), not the most
+// any input could need -- the lists grow between rounds when an input leaves more, smaller segments (lists_reserve).
+// (Round 2 reserved n / 1024 + 6 n / leaf capacity entries, 1.5 times over: 189 MB of the 646 MB at 2^30 u32 keys.)
 template <typename K, typename V> static uint64_t leaf_list_guess(uint64_t n)
 {
-	using C = Cfg<K, V>;
-	const uint64_t small_max = (uint64_t)C::SORT_TH * C::SORT_KPT;
-	return std::min<uint64_t>(n / 1024 + 6 * n / small_max + 4096, n / 2 + 16);
+	return std::min<uint64_t>(n / 8192 + 4096, n / 2 + 16);
 }
 
 template <typename K, typename V> static size_t keep_bytes_for(uint64_t n)
@@ -488,7 +492,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 
 	// ---- buffers that live for the whole call
 	{
-		int rc = keep_reserve(c, keep_bytes_for<K, V>(n));
+		int rc = keep_reserve(c, keep_bytes_for<K, V>(n), true);
 		if (!rc) rc = pinned_reserve(c, 1 << 16);
 		if (!rc) rc = lists_reserve(c, 4096, 0, 0);
 		if (rc) return rc;
@@ -808,7 +812,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			carve_round<K, V>(sz, rp, small_max, rb);
 			size_t need = sz.off + 4096;
 			if (round == 0 && !single_pass) need = std::max(need, round_bytes_estimate<K, V>(n, c->sm_count));
-			int rc = slab_reserve(c, need); // between rounds nothing in the slab is live
+			int rc = slab_reserve(c, need, round == 0); // between rounds nothing in the slab is live
 			if (rc) return rc;
 			Bump b(c->slab);
 			carve_round<K, V>(b, rp, small_max, rb);
@@ -1414,10 +1418,10 @@ int msd_reserve(msd_ctx *c, uint64_t n, int key_bytes, int val_bytes)
 		list_n = leaf_list_guess<uint64_t, uint64_t>(n);
 	} else
 		return fail(c, MSD_EINVAL, "unsupported element layout %d+%d bytes", key_bytes, val_bytes);
-	int rc = slab_reserve(c, round_b);
-	if (!rc) rc = keep_reserve(c, keep_b);
+	int rc = slab_reserve(c, round_b, true);
+	if (!rc) rc = keep_reserve(c, keep_b, true);
 	if (!rc) rc = pinned_reserve(c, 1 << 20);
-	if (!rc) rc = lists_reserve(c, list_n, 0, 0);
+	if (!rc) rc = lists_reserve(c, list_n, 0, 0, true);
 	return rc;
 }
 
