@@ -71,7 +71,8 @@ def kernel_algo(cfg):
         "A classify direct": (f"classify_direct2_kernel<{t}>", 2 * (K + V)),
         "A histogram": (f"direct_hist_kernel<{t}>", K),
         "B block permute": (f"chains_kernel<{t}>", rnd / 2),
-        "LDS sort": (f"leaf_count_sort_kernel<{t}>", None),
+        # (u64 keys: the segments two rounds leave are finished by leaf17_kernel<NoVal>, launched in this phase)
+        "LDS sort": ("leaf17_kernel<NoVal>" if t == "u64" else f"leaf_count_sort_kernel<{t}>", None),
         "leaf17": ("leaf17_kernel<u64>", None),
         "count sort": ("count_place16_kernel" if t == "u32" else f"count_place_kernel<{t}>", None),
         "big count sort": (f"bigcount_write_kernel<{t}>", None),

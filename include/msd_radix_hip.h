@@ -143,7 +143,14 @@ int msd_gather_runs_u64(msd_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, co
  *     fails with MSD_EINVAL and writes nothing if the counts do not add up to it).  d_src (src_cap elements) and
  *     d_dst must not overlap.  nsrc <= 8.  Blocks the calling thread until the leaf has run (one small readback:
  *     buckets it did not take -- longer than 17408 keys, more than 255 copies of one key -- are finished by the
- *     general leaves, msd_stat "merge_rejected"). */
+ *     general leaves, msd_stat "merge_rejected").
+ *   msd_pack_low16_u32 / msd_merge_buckets_u32_low16: once a shard is ordered by its keys' UPPER halves, the upper half of
+ *     every key is the number of its bucket, which sender and receiver know from the counts: only the LOW halves need to
+ *     cross the links.  msd_pack_low16_u32 writes the low 16 bits of the n keys, in order, to d_out (n uint16; no overlap
+ *     with d_keys; asynchronous); msd_merge_buckets_u32_low16 is msd_merge_buckets_u32 with open_bits = 16 for extents of
+ *     such low halves (d_src, src_cap and src_base in uint16 elements) and writes whole keys.  Half the exchange volume --
+ *     the exchange is what bounds a step at 2 and 4 GPUs (one xGMI link per pair) -- for one more pass over the shard
+ *     (6 bytes per key) before it. */
 int msd_sort_u32_top(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, int end_bit, int begin_bit);
 int msd_sort_u64_top(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, int end_bit, int begin_bit);
 int msd_sort_pairs_u64_top(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n, int end_bit, int begin_bit);
@@ -152,6 +159,9 @@ int msd_bucket_bounds_u64(msd_ctx *ctx, const uint64_t *d_keys, uint64_t n, unsi
 int msd_merge_buckets_u32(msd_ctx *ctx, const uint32_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base,
 			  uint32_t nsrc, uint32_t nbuckets, int open_bits, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap,
 			  uint64_t n_expected);
+int msd_pack_low16_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint16_t *d_out);
+int msd_merge_buckets_u32_low16(msd_ctx *ctx, const uint16_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base,
+				uint32_t nsrc, uint32_t nbuckets, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected);
 
 /* ---- splitter service: sample -> sort (msd_sort_u32) -> delimiters -> range partition ----
  * The reference's front end for skewed keys (src/msb_64.c:1511-1564): a random sample of the
@@ -232,8 +242,9 @@ int msd_plan_first_round(uint64_t n, int key_bytes, int val_bytes, int end_bit, 
  *   profiles/r02_sq_counters.json and r02_stamps_classify_direct_before.json keep its measurements).
  * "count16": u32 keys with 16 open bits: 1 (default) = count_place16_kernel for segments of about 2^14
  *   keys, 2 = always, 0 = never (count_place_kernel).
- * "leaf17": tuples: 1 (default) = segments of <= 17408 tuples are finished in one pass by leaf17_kernel (read once,
- *   sorted in registers and LDS, written once), 0 = register partition + the small leaves (round 2).
+ * "leaf17": u64 keys and tuples: 1 (default) = segments of <= 17408 elements are finished in one pass by leaf17_kernel (read
+ *   once, sorted in registers and LDS, written once), 0 = tuples: register partition + the small leaves, u64 keys:
+ *   leaf_count_sort_kernel (round 2).
  * "stream_kernel": the streaming classify of rounds that do not place directly: 2 (default) = classify_stream2_kernel
  *   (one fetch-add per key, no per-key second pass), 1 = round 2's classify_kernel.
  * "mid_leaf": u32 keys: 1 (default) = counting-leaf segments the register-resident kernels do not take (17 Ki .. 128 Ki

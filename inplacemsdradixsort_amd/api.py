@@ -114,8 +114,20 @@ class MsdContext:
         nsrc, nb = int(counts.shape[0]), int(counts.shape[1])
         if len(src_base) != nsrc:
             raise MsdError("merge_buckets: one base offset per source row")
+        if src.element_size() == 2:   # extents of low halves (pack_low16): the upper half of a key is its bucket's number
+            if open_bits != 16:
+                raise MsdError("merge_buckets: extents of low halves need 16 open bits")
+            self._ok(self._L.msd_merge_buckets_u32_low16(self._h, self._ptr(src, 2), src.numel(), self._ptr(counts, 8), self._u64arr(src_base),
+                                                         nsrc, nb, first_prefix, self._ptr(dst, 4), dst.numel(), n_expected))
+            return
         self._ok(self._L.msd_merge_buckets_u32(self._h, self._ptr(src, 4), src.numel(), self._ptr(counts, 8), self._u64arr(src_base),
                                                nsrc, nb, open_bits, first_prefix, self._ptr(dst, 4), dst.numel(), n_expected))
+
+    def pack_low16(self, keys, out) -> None:
+        """``out`` (int16, >= keys.numel() elements) <- the low 16 bits of the u32 ``keys``, in order."""
+        if keys.element_size() != 4 or out.element_size() != 2 or out.numel() < keys.numel():
+            raise MsdError("pack_low16: u32 keys, an int16 buffer at least as long")
+        self._ok(self._L.msd_pack_low16_u32(self._h, self._ptr(keys, 4), keys.numel(), self._ptr(out, 2)))
 
     # ---- building blocks
     def histogram(self, keys, shift: int, radix_bits: int):

@@ -395,8 +395,10 @@ constexpr uint64_t kMcMaxKeys = (uint64_t)kMcSeg * (kMcMaxSegs - 1);
 constexpr size_t kMcLds = ((size_t)kMcCwWords + 272 + (kMcTh / 64) * kMcSeg + 16 + 4 + 48 + (kMcMaxSegs + 4) / 2) * 4;
 static_assert(kMcLds <= 160 * 1024, "one workgroup per CU");
 
-template <bool LIST>
-__global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src, uint32_t *dst,
+// IN = uint16_t (extent mode, 16 open bits): the extents hold only the keys' LOW halves -- the upper half of a key is its
+// bucket's number, which the receiver of a multi-GPU exchange knows; half the bytes cross the links and half are read here.
+template <bool LIST, typename IN = uint32_t>
+__global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint32_t *dst,
 	const uint32_t *__restrict__ cnt32, const uint64_t *__restrict__ src_off, const uint64_t *__restrict__ dst_off,
 	uint32_t nsrc, uint32_t nb, uint32_t bits_arg, uint32_t prefix0,
 	const Segment *__restrict__ segs, const uint32_t *__restrict__ nsegs_dev,
@@ -404,6 +406,9 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 	const uint32_t *__restrict__ status)
 {
 	constexpr int TH = kMcTh;
+	constexpr bool IN16 = sizeof(IN) == 2;
+	constexpr uint32_t VE = 16 / sizeof(IN); // elements per 16-byte vector
+	static_assert(!LIST || !IN16, "a list's segments are sorted where they are: whole keys");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem); // 2 x 16-bit counters per word, later offsets inside the value's group
 	uint32_t *gbase = cw + kMcCwWords;                 // 257 group bases
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 			d = rfl64(dst_off[cur]);
 			n64 = rfl64(dst_off[cur + 1]) - d;
 		}
-		const bool bits_ok = bits >= 1 && bits <= 16;
+		const bool bits_ok = bits >= 1 && bits <= 16 && (!IN16 || bits == 16);
 		const uint32_t mask = bits_ok ? (1u << bits) - 1u : 0u;
 		if constexpr (LIST)
 			hi = n64 ? rfl(src[d]) & ~mask : 0u; // (read before anything is written: the sort is in place)
@@ -496,16 +501,16 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 				(void)__hip_atomic_fetch_add(&cw[c16_at(v >> 1)], 1u << ((v & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			};
 			// ---- count: the partial vectors at both ends of every extent element by element ...
-			if (tid < 4) {
+			if (tid < VE) {
 				for (uint32_t x = 0; x < nx; ++x) {
 					uint64_t s;
 					uint32_t len;
 					extent(x, s, len);
 					if (len == 0) continue;
-					const uint32_t o = (uint32_t)(s & 3u), tot = len + o, vend = tot >> 2;
-					const uint32_t *base = src + (s - o);
+					const uint32_t o = (uint32_t)(s & (VE - 1u)), tot = len + o, vend = tot / VE;
+					const IN *base = src + (s - o);
 					if (o && tid >= o && tid < tot) count(base[tid]);
-					const uint32_t el = (vend << 2) + tid;
+					const uint32_t el = vend * VE + tid;
 					if (el < tot && (vend > 0 || o == 0)) count(base[el]);
 				}
 			}
@@ -518,8 +523,8 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 					uint64_t s;
 					uint32_t len;
 					extent(bx, s, len);
-					const uint32_t o = (uint32_t)(s & 3u), tot = len + o;
-					const uint32_t vfirst = o ? 1u : 0u, vend = tot >> 2;
+					const uint32_t o = (uint32_t)(s & (VE - 1u)), tot = len + o;
+					const uint32_t vfirst = o ? 1u : 0u, vend = tot / VE;
 					if (len && vend > vfirst) {
 						bbase = reinterpret_cast<const u32x4 *>(src + (s - o));
 						bi = vfirst;
@@ -555,6 +560,12 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 						count(q[u].y);
 						count(q[u].z);
 						count(q[u].w);
+						if constexpr (IN16) { // (eight low halves per vector; count() masks the value)
+							count(q[u].x >> 16);
+							count(q[u].y >> 16);
+							count(q[u].z >> 16);
+							count(q[u].w >> 16);
+						}
 					}
 				}
 			};
@@ -714,7 +725,7 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 					uint64_t s;
 					uint32_t len;
 					extent(x, s, len);
-					for (uint32_t i = tid; i < len; i += TH) dst[at + i] = src[s + i];
+					for (uint32_t i = tid; i < len; i += TH) dst[at + i] = IN16 ? (hi | (uint32_t)src[s + i]) : (uint32_t)src[s + i];
 					at += len;
 				}
 			}
@@ -731,6 +742,19 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const uint32_t *src,
 		__syncthreads();
 	}
 	MSD_STAMP_FLUSH(TH / 64);
+}
+
+// the low halves of n u32 keys, in order (what a rank sends once its shard is ordered by the keys' upper halves)
+__global__ __launch_bounds__(256) void pack_low16_kernel(const uint32_t *__restrict__ keys, uint64_t n, uint16_t *__restrict__ out)
+{
+	const uint64_t nv = n >> 3, step = (uint64_t)gridDim.x * 256;
+	for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += step) {
+		const u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(keys) + 2 * v);
+		const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(keys) + 2 * v + 1);
+		const u32x4 o = { (a.x & 0xFFFFu) | (a.y << 16), (a.z & 0xFFFFu) | (a.w << 16), (b.x & 0xFFFFu) | (b.y << 16), (b.z & 0xFFFFu) | (b.w << 16) };
+		__builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(out) + v);
+	}
+	if (blockIdx.x == 0 && threadIdx.x < (n & 7u)) out[(nv << 3) + threadIdx.x] = (uint16_t)keys[(nv << 3) + threadIdx.x];
 }
 
 // first index i with (keys[i] >> shift) >= first + b, b = 0 .. nbuckets: the boundaries of the buckets of an array that

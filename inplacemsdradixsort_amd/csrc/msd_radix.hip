@@ -1271,9 +1271,11 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_place16_kernel<8>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kC16Lds));
-			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false>),
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false, uint32_t>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
-			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<true>),
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false, uint16_t>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<true, uint32_t>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
 		}
 		HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&count_place_kernel<K>),
@@ -1505,19 +1507,22 @@ static int bounds_impl(msd_ctx *c, const K *k, uint64_t n, unsigned shift, uint6
 }
 
 // The counting leaf of a rank after a fine-grained exchange (msd_merge16.hpp): every bucket = nsrc extents in d_src.
-static int merge_impl(msd_ctx *c, const uint32_t *src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
+template <typename IN>
+static int merge_impl(msd_ctx *c, const IN *src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
 		      uint32_t nb, int open_bits, uint32_t first_prefix, uint32_t *dst, uint64_t dst_cap, uint64_t n_expected)
 {
+	constexpr bool IN16 = sizeof(IN) == 2;
 	if (!c) return MSD_EINVAL;
 	if (!src || !dst || !d_counts || !src_base) return fail(c, MSD_EINVAL, "merge_buckets: null pointer");
 	if (nsrc < 1 || nsrc > 8) return fail(c, MSD_EINVAL, "merge_buckets: 1..8 source runs per bucket");
 	if (nb == 0 || nb > (1u << 24)) return fail(c, MSD_EINVAL, "merge_buckets: bucket count out of range");
 	if (open_bits < 1 || open_bits > 16) return fail(c, MSD_EINVAL, "merge_buckets: 1..16 open bits");
+	if (IN16 && open_bits != 16) return fail(c, MSD_EINVAL, "merge_buckets: extents of low halves need 16 open bits");
 	if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(c, MSD_EINVAL, "merge_buckets: buffers must be 16-byte aligned");
 	if (n_expected > dst_cap) return fail(c, MSD_EINVAL, "merge_buckets: the output buffer is too small");
 	if ((uint64_t)first_prefix + nb > (1ull << (32 - open_bits))) return fail(c, MSD_EINVAL, "merge_buckets: bucket numbers exceed the key's prefix");
 	{ // the buffers must not overlap (the leaf reads extents while other workgroups write finished buckets)
-		const uintptr_t s0 = (uintptr_t)src, s1 = s0 + src_cap * 4, d0 = (uintptr_t)dst, d1 = d0 + dst_cap * 4;
+		const uintptr_t s0 = (uintptr_t)src, s1 = s0 + src_cap * sizeof(IN), d0 = (uintptr_t)dst, d1 = d0 + dst_cap * 4;
 		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "merge_buckets: source and destination overlap");
 	}
 	HIPCHK(c, hipSetDevice(c->device));
@@ -1550,18 +1555,25 @@ static int merge_impl(msd_ctx *c, const uint32_t *src, uint64_t src_cap, const u
 	hipLaunchKernelGGL(merge_plan_kernel, dim3(nsrc + 1), dim3(1024), 0, c->stream, d_counts, mb, nsrc, nb, n_expected, cnt32, soff, doff, status);
 	// buckets that fit the registers of a workgroup (shards of <= 2^27 keys at 8 ranks) take merge_place16_kernel, larger
 	// ones (2^30 keys per rank: nsrc x 2^14 keys per bucket) merge_count_kernel
-	const bool in_regs = c->merge_leaf == 1 || (c->merge_leaf == 0 && n_expected / nb <= 12000 && open_bits >= (int)kC16MinBits);
-	if (in_regs) {
+	// (low halves: merge_count_kernel at every bucket size -- shorter buckets cost it more per key, the exchange it follows
+	// cost half)
+	const bool in_regs = !IN16 && (c->merge_leaf == 1 || (c->merge_leaf == 0 && n_expected / nb <= 12000 && open_bits >= (int)kC16MinBits));
+	if constexpr (IN16) {
+		const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)c->sm_count);
+		hipLaunchKernelGGL((merge_count_kernel<false, uint16_t>), dim3(grid), dim3(kMcTh), kMcLds, c->stream, src, dst, (const uint32_t *)cnt32,
+				   (const uint64_t *)soff, (const uint64_t *)doff, nsrc, nb, (uint32_t)open_bits, first_prefix, (const Segment *)nullptr,
+				   (const uint32_t *)nullptr, rej, &ctr->nslow16, &ctr->count_ticket3, (const uint32_t *)status);
+	} else if (in_regs) {
 		const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)c->sm_count * 2);
 		const uint32_t G = nsrc <= 2 ? 2 : nsrc <= 4 ? 4 : 8;
 #define MSD_MERGE_LAUNCH(GG)                                                                                                              \
-	hipLaunchKernelGGL((merge_place16_kernel<GG>), dim3(grid), dim3(kC16Th), kC16Lds, c->stream, src, src_cap, dst, (const uint32_t *)cnt32, \
+	hipLaunchKernelGGL((merge_place16_kernel<GG>), dim3(grid), dim3(kC16Th), kC16Lds, c->stream, (const uint32_t *)src, src_cap, dst, (const uint32_t *)cnt32, \
 			   (const uint64_t *)soff, (const uint64_t *)doff, nsrc, nb, (uint32_t)open_bits, first_prefix, rej, ctr, (const uint32_t *)status)
 		if (G == 2) MSD_MERGE_LAUNCH(2); else if (G == 4) MSD_MERGE_LAUNCH(4); else MSD_MERGE_LAUNCH(8);
 #undef MSD_MERGE_LAUNCH
 	} else {
 		const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)c->sm_count);
-		hipLaunchKernelGGL((merge_count_kernel<false>), dim3(grid), dim3(kMcTh), kMcLds, c->stream, src, dst, (const uint32_t *)cnt32,
+		hipLaunchKernelGGL((merge_count_kernel<false, uint32_t>), dim3(grid), dim3(kMcTh), kMcLds, c->stream, (const uint32_t *)src, dst, (const uint32_t *)cnt32,
 				   (const uint64_t *)soff, (const uint64_t *)doff, nsrc, nb, (uint32_t)open_bits, first_prefix, (const Segment *)nullptr,
 				   (const uint32_t *)nullptr, rej, &ctr->nslow16, &ctr->count_ticket3, (const uint32_t *)status);
 	}
@@ -1602,7 +1614,28 @@ int msd_bucket_bounds_u64(msd_ctx *c, const uint64_t *k, uint64_t n, unsigned sh
 int msd_merge_buckets_u32(msd_ctx *c, const uint32_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
 			  uint32_t nbuckets, int open_bits, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected)
 {
-	return merge_impl(c, d_src, src_cap, d_counts, src_base, nsrc, nbuckets, open_bits, first_prefix, d_dst, dst_cap, n_expected);
+	return merge_impl<uint32_t>(c, d_src, src_cap, d_counts, src_base, nsrc, nbuckets, open_bits, first_prefix, d_dst, dst_cap, n_expected);
+}
+int msd_merge_buckets_u32_low16(msd_ctx *c, const uint16_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
+				uint32_t nbuckets, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected)
+{
+	return merge_impl<uint16_t>(c, d_src, src_cap, d_counts, src_base, nsrc, nbuckets, 16, first_prefix, d_dst, dst_cap, n_expected);
+}
+int msd_pack_low16_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, uint16_t *d_out)
+{
+	if (!c) return MSD_EINVAL;
+	if (n == 0) return MSD_OK;
+	if (!d_keys || !d_out) return fail(c, MSD_EINVAL, "pack_low16: null pointer");
+	if (((uintptr_t)d_keys & 15) || ((uintptr_t)d_out & 15)) return fail(c, MSD_EINVAL, "pack_low16: buffers must be 16-byte aligned");
+	{
+		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * 4, d0 = (uintptr_t)d_out, d1 = d0 + n * 2;
+		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "pack_low16: source and destination overlap");
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	const unsigned grid = (unsigned)std::min<uint64_t>((uint64_t)c->sm_count * 16, (n / 8 + 255) / 256 + 1);
+	hipLaunchKernelGGL(pack_low16_kernel, dim3(grid), dim3(256), 0, c->stream, d_keys, n, d_out);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
 }
 
 // ---- segmented sort and run gather: what a rank of the multi-GPU sort does with the keys it received
