@@ -49,6 +49,9 @@ int msd_shard_destroy(msd_shard *sh);
 /* "force_exchange" (tests): 1 = a single rank WITH a communicator runs the whole exchange -- count all-gather, grouped
  * send / receive to itself, the leaf over the "arrived" extents -- instead of sorting locally: all of the N > 1 code that
  * one GPU can execute through RCCL. */
+/* "low16" (default 1): the fine scheme exchanges only the low halves of the keys -- the upper half of a key is its
+ * bucket's number once the shard is ordered by it (msd_pack_low16_u32 / msd_merge_buckets_u32_low16): half the bytes over
+ * xGMI for one more pass over the shard.  0 = whole keys travel.  All ranks must use the same value. */
 int msd_shard_set_option(msd_shard *sh, const char *name, int64_t value);
 int msd_shard_rank(const msd_shard *sh);
 int msd_shard_world(const msd_shard *sh);
@@ -58,9 +61,10 @@ const char *msd_shard_last_error(const msd_shard *sh);
  * *d_out points at this rank's sorted key range (*n_out keys; rank r's keys precede rank r + 1's) -- inside d_work
  * when the fine scheme ran, inside d_recv otherwise, d_keys itself for a single rank.
  *   fine scheme   (d_work != NULL, 2..8 ranks, n >= 2^27 on every rank, or forced): the shard is ordered by its top 16
- *                 bits, the 2^16 bucket counts are all-gathered, one all-to-all, one counting pass over the arrived
- *                 extents writes the sorted buckets into d_work (msd_sort_u32_top / msd_bucket_bounds_u32 /
- *                 msd_merge_buckets_u32 of msd_radix_hip.h).
+ *                 bits, the 2^16 bucket counts are all-gathered, one all-to-all (of the keys' low halves, packed into
+ *                 d_work: option "low16"), one counting pass over the arrived extents writes the sorted buckets into
+ *                 d_work (msd_sort_u32_top / msd_bucket_bounds_u32 / msd_pack_low16_u32 / msd_merge_buckets_u32_low16 of
+ *                 msd_radix_hip.h).
  *   coarse scheme one in-place top-digit pass, the 256 bucket counts are all-gathered, one all-to-all, the arrived keys
  *                 are sorted in d_recv on their low 32 - log2(ranks) bits (msd_partition_u32 / msd_sort_u32_bits).
  * recv_cap / work_cap: elements; the call returns MSD_EOVERFLOW on every rank if some rank's range does not fit.

@@ -37,6 +37,7 @@ struct msd_shard {
 	uint64_t *d_row = nullptr, *d_all = nullptr, *d_small = nullptr, *d_mine = nullptr, *d_bounds = nullptr;
 	uint64_t *h_small = nullptr; // pinned
 	bool force_exchange = false; // (tests) a single rank with a communicator goes through the whole exchange instead of sorting locally
+	bool low16 = true;           // fine scheme: only the low halves of the keys are exchanged ("low16" = 0: whole keys; all ranks alike)
 	std::string err;
 };
 
@@ -163,7 +164,9 @@ int finish_coarse_row(msd_shard *sh, uint64_t cap, uint64_t n)
 template <typename T>
 int all_to_all(msd_shard *sh, const T *src, T *dst, const std::vector<uint64_t> &send_cnt, const std::vector<uint64_t> &recv_cnt, bool group_open)
 {
-	const ncclDataType_t ty = sizeof(T) == 4 ? ncclUint32 : ncclUint64;
+	// (16-bit elements travel as twice as many bytes: RCCL has no 16-bit integer type)
+	const ncclDataType_t ty = sizeof(T) == 4 ? ncclUint32 : sizeof(T) == 8 ? ncclUint64 : ncclUint8;
+	const uint64_t per = sizeof(T) == 2 ? 2 : 1; // RCCL elements per element of T
 	if (!group_open) SH_NCCL(sh, ncclGroupStart());
 	// RCCL 2.26 (ROCm 7) moves only half of a single send / receive of >= 2 GiB, silently (tools/debug/a2a_big.py: measured on
 	// the GPU box, through torch.distributed and through ncclSend / ncclRecv alike): every pair's block goes in pieces of
@@ -172,9 +175,9 @@ int all_to_all(msd_shard *sh, const T *src, T *dst, const std::vector<uint64_t> 
 	uint64_t so = 0, ro = 0;
 	for (int p = 0; p < sh->world; ++p) {
 		for (uint64_t a = 0; a < send_cnt[p]; a += lim)
-			SH_NCCL(sh, ncclSend(src + so + a, std::min(lim, send_cnt[p] - a), ty, p, sh->comm, sh->stream));
+			SH_NCCL(sh, ncclSend(src + so + a, std::min(lim, send_cnt[p] - a) * per, ty, p, sh->comm, sh->stream));
 		for (uint64_t a = 0; a < recv_cnt[p]; a += lim)
-			SH_NCCL(sh, ncclRecv(dst + ro + a, std::min(lim, recv_cnt[p] - a), ty, p, sh->comm, sh->stream));
+			SH_NCCL(sh, ncclRecv(dst + ro + a, std::min(lim, recv_cnt[p] - a) * per, ty, p, sh->comm, sh->stream));
 		so += send_cnt[p];
 		ro += recv_cnt[p];
 	}
@@ -243,6 +246,10 @@ int msd_shard_set_option(msd_shard *sh, const char *name, int64_t value)
 		sh->force_exchange = value != 0;
 		return MSD_OK;
 	}
+	if (!strcmp(name, "low16")) {
+		sh->low16 = value != 0;
+		return MSD_OK;
+	}
 	return fail(sh, MSD_EINVAL, "unknown option %s", name);
 }
 
@@ -292,7 +299,16 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 		SH_HIP(sh, hipGetLastError());
 		int rc = exchange_counts(sh, kFineBuckets, kRowLen, "keys", send_cnt, recv_cnt);
 		if (rc) return rc;
-		rc = all_to_all<uint32_t>(sh, d_keys, d_recv, send_cnt, recv_cnt, false);
+		// Only the keys' LOW halves travel: the shard is ordered by the upper halves, so the upper half of a key is its bucket's
+		// number, which the receiver knows from the counts.  They are packed into the work buffer (dead until the leaf writes
+		// it) and arrive in the receive buffer as uint16 -- half the bytes over the links (one xGMI link per pair of GPUs: at
+		// 2^30 keys per rank the exchange of whole keys outlasts a rank's local work at 2 and 4 GPUs) and for the leaf to read.
+		const bool low16 = sh->low16 && work_cap * 2 >= n;
+		if (low16) {
+			SH_MSD(sh, msd_pack_low16_u32(sh->ctx, d_keys, n, (uint16_t *)d_work));
+			rc = all_to_all<uint16_t>(sh, (const uint16_t *)d_work, (uint16_t *)d_recv, send_cnt, recv_cnt, false);
+		} else
+			rc = all_to_all<uint32_t>(sh, d_keys, d_recv, send_cnt, recv_cnt, false);
 		if (rc) return rc;
 		hipLaunchKernelGGL(mine_kernel, dim3((kFineBuckets + 255) / 256), dim3(256), 0, sh->stream, (const uint64_t *)sh->d_all, kRowLen, per,
 				   (uint32_t)sh->rank, (uint32_t)W, sh->d_mine);
@@ -303,8 +319,12 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 			base[s] = m;
 			m += recv_cnt[s];
 		}
-		SH_MSD(sh, msd_merge_buckets_u32(sh->ctx, d_recv, recv_cap, sh->d_mine, base.data(), (uint32_t)W, per, 32 - kFineBits,
-						 (uint32_t)sh->rank * per, d_work, work_cap, m));
+		if (low16)
+			SH_MSD(sh, msd_merge_buckets_u32_low16(sh->ctx, (const uint16_t *)d_recv, recv_cap * 2, sh->d_mine, base.data(), (uint32_t)W, per,
+							       (uint32_t)sh->rank * per, d_work, work_cap, m));
+		else
+			SH_MSD(sh, msd_merge_buckets_u32(sh->ctx, d_recv, recv_cap, sh->d_mine, base.data(), (uint32_t)W, per, 32 - kFineBits,
+							 (uint32_t)sh->rank * per, d_work, work_cap, m));
 		SH_HIP(sh, hipStreamSynchronize(sh->stream));
 		*d_out = d_work;
 		*n_out = m;

@@ -101,6 +101,11 @@ class _Splits(list):
 def all_to_all_v(dist, out, inp, got_l, send_l, group=None, async_op: bool = False):
     """``out`` <- all-to-all(v) of ``inp`` with the given split sizes, in rounds of at most A2A_MAX_BYTES per pair (one
     ``all_to_all_single`` when every block is small).  Returns the list of Work handles (``async_op``) or []."""
+    if inp.element_size() == 2:   # (neither RCCL nor gloo moves 16-bit integers: the same bytes as uint8, twice the counts)
+        import torch
+        send2 = _Splits([2 * int(x) for x in send_l])
+        send2.max_block = 2 * getattr(send_l, "max_block", 0)
+        return all_to_all_v(dist, out.view(torch.uint8), inp.view(torch.uint8), [2 * int(x) for x in got_l], send2, group, async_op)
     lim = A2A_MAX_BYTES // inp.element_size()
     world = len(send_l)
     big = max(getattr(send_l, "max_block", 0), max(list(send_l) + list(got_l) + [0]))
@@ -246,6 +251,20 @@ def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
     return send_l, to_rank_h[:, me].tolist(), mine
 
 
+# The fine scheme exchanges only the keys' LOW halves: once the shard is ordered by its top 16 bits the upper half of a
+# key is its bucket's number, which every receiver knows from the all-gathered counts.  Half the bytes cross xGMI -- one
+# link per pair of GPUs: at 2^30 keys per rank a pair exchanges 2 GiB at 2 ranks, 1 GiB at 4, which takes longer than
+# all of a rank's local work -- and the counting leaf reads half as much; the price is one more pass over the shard
+# (read 4, write 2 bytes per key: engine.pack_low16).  (False: whole keys travel; tests and A/B comparisons)
+FINE_LOW16 = True
+
+
+def _as_low16(buf):
+    """The int16 view of an int32 buffer (twice the elements)."""
+    import torch
+    return buf.view(torch.int16)
+
+
 def _fine_counts(engine, keys):
     """Orders the shard by its top 16 bits and returns its 2^16 bucket sizes (int64, on the device)."""
     engine.sort_top(keys, 32 - FINE_BITS)
@@ -306,6 +325,13 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
     if use_fine(keys.numel(), world, work is not None, scheme, _force_exchange):
         send_l, got_l, mine = exchange_fine_counts(dist, _fine_counts(engine, keys), min(recv.numel(), work.numel()), world, group)
         m = int(sum(got_l))
+        if FINE_LOW16 and 2 * work.numel() >= keys.numel():
+            # the low halves are packed into the work buffer (dead until the leaf writes it) and arrive in the receive
+            # buffer as int16; the leaf puts the upper halves back
+            w16, r16 = _as_low16(work), _as_low16(recv)
+            engine.pack_low16(keys, w16)
+            all_to_all_v(dist, r16[:m], w16[:keys.numel()], got_l, send_l, group)
+            return _fine_finish(engine, r16, work, mine, got_l, _rank(dist, group), world)
         all_to_all_v(dist, recv[:m], keys, got_l, send_l, group)
         return _fine_finish(engine, recv, work, mine, got_l, _rank(dist, group), world)
     counts = engine.partition(keys, 24, 8)                       # int64[256], device of `keys`
@@ -403,6 +429,7 @@ class ShardedSorter:
         self._slot = 0
         self._pending = []
         self._async = None
+        self._send16 = []                 # fine scheme: the packed low halves of the shards whose exchange is in flight
 
     def _all_to_all(self, out, keys, got_l, send_l):
         # torch.distributed returns Work handles whose wait() orders the current stream after the exchange; stand-ins without
@@ -426,7 +453,22 @@ class ShardedSorter:
         if use_fine(keys.numel(), self.world, bool(self.fine_work), self.scheme, self._force):
             cap = min(recv.numel(), min(w.numel() for w in self.fine_work))
             send_l, got_l, mine = exchange_fine_counts(self.dist, _fine_counts(self.engine, keys), cap, self.world, self.group)  # raises on all ranks
+            slot = self._slot
             self._slot = (self._slot + 1) % len(self.recv)
+            if FINE_LOW16:
+                # only the low halves travel (module comment at FINE_LOW16): packed into a send buffer of this sorter -- one
+                # per exchange in flight --, received as int16
+                while len(self._send16) < len(self.recv):
+                    self._send16.append(None)
+                if self._send16[slot] is None or self._send16[slot].numel() < keys.numel():
+                    import torch
+                    self._send16[slot] = torch.empty(keys.numel(), dtype=torch.int16, device=keys.device)
+                packed = self._send16[slot][:keys.numel()]
+                self.engine.pack_low16(keys, packed)
+                r16 = _as_low16(recv)
+                out = r16[:int(sum(got_l))]
+                self._pending.append((out, self._all_to_all(out, packed, got_l, send_l), ("fine", r16, mine, got_l)))
+                return
             out = recv[:int(sum(got_l))]
             self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), ("fine", recv, mine, got_l)))
             return

@@ -55,8 +55,12 @@ class NumpyEngine:
         assert (np.diff(a.astype(np.int64)) >= 0).all()
         return torch.from_numpy(np.searchsorted(a, np.arange(first, first + nbuckets + 1, dtype=np.uint64), side="left").astype(np.int64))
 
+    def pack_low16(self, keys, out):
+        out.numpy().view(np.uint16)[:keys.numel()] = keys.numpy().view(np.uint32).astype(np.uint16)
+
     def merge_buckets(self, src, counts, src_base, open_bits, first_prefix, dst, n_expected):
-        s_, d, c = src.numpy().view(np.uint32), dst.numpy().view(np.uint32), counts.numpy()
+        low16 = src.element_size() == 2          # extents of low halves: the upper half of a key is its bucket's number
+        s_, d, c = src.numpy().view(np.uint16 if low16 else np.uint32), dst.numpy().view(np.uint32), counts.numpy()
         nsrc, nb = c.shape
         assert int(c.sum()) == n_expected <= d.size
         pos = [int(b) for b in src_base]
@@ -67,6 +71,9 @@ class NumpyEngine:
                 parts.append(s_[pos[x]:pos[x] + int(c[x, j])])
                 pos[x] += int(c[x, j])
             b = np.concatenate(parts) if parts else np.zeros(0, np.uint32)
+            if low16:
+                assert open_bits == 16
+                b = b.astype(np.uint32) | np.uint32((first_prefix + j) << 16)
             assert ((b >> np.uint32(open_bits)) == first_prefix + j).all()   # every extent holds keys of its bucket only
             d[at:at + b.size] = np.sort(b)
             at += b.size

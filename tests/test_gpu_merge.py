@@ -189,6 +189,70 @@ def test_merge_counting_kernel_duplicates(ctx):
     assert ctx.stats().get("merge_rejected", 0) == 2
 
 
+def _low16_arrivals(src, counts, base):
+    """The same arrival buffer holding only the keys' low halves: every offset counts uint16 elements."""
+    return (src & np.uint32(0xFFFF)).astype(np.uint16), base
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 1000, (1 << 20) + 5, 1 << 24])
+def test_pack_low16(ctx, n):
+    import torch
+    from oracle import oracle as O
+    k = O.gen_uniform_u32(n, seed=n + 1) if n else np.zeros(0, dtype=np.uint32)
+    out = torch.full((n + 8,), -1, dtype=torch.int16, device="cuda")
+    ctx.pack_low16(dev(k), out)
+    got = out.cpu().numpy().view(np.uint16)
+    assert (got[:n] == (k & np.uint32(0xFFFF)).astype(np.uint16)).all() and (got[n:] == 0xFFFF).all()
+
+
+@pytest.mark.parametrize("nsrc,nb,per_bucket", [
+    (8, 24, 131072), (4, 40, 65536), (2, 64, 32768),                   # 2^30 keys per rank: nsrc x 2^14 keys per bucket
+    (3, 50, 40000), (8, 300, 3000), (1, 10, 200000), (8, 2000, 5), (5, 6, 700000), (2, 512, 4096), (8, 512, 16384),
+])
+def test_merge_buckets_from_low_halves(ctx, nsrc, nb, per_bucket):
+    """msd_merge_buckets_u32_low16: the extents hold uint16 low halves (what the fine exchange moves), the leaf puts the
+    bucket numbers back: the output equals the sort of the whole keys."""
+    import torch
+    rng = np.random.default_rng(nsrc * 91 + nb)
+    first = 3 * nb
+    gaps = [int(g) for g in rng.integers(0, 13, nsrc)]
+    src, counts, base, allk = _arrivals(rng, nsrc, nb, first, 16, per_bucket, gaps)
+    counts[:, nb // 2] = 0                                            # an empty bucket in the middle
+    src, allk = _rebuild(src, counts, base, gaps, first, 16, rng)
+    s16, base16 = _low16_arrivals(src, counts, base)
+    n = int(counts.sum())
+    dst = torch.full((n + 5,), -1, dtype=torch.int32, device="cuda")
+    t16 = torch.from_numpy(s16.view(np.int16)).cuda()
+    ctx.merge_buckets(t16, torch.from_numpy(counts).cuda(), base16, 16, first, dst, n)
+    out = host(dst, np.uint32)
+    assert (out[:n] == np.sort(allk)).all()
+    assert (out[n:] == 0xFFFFFFFF).all()
+
+
+def test_merge_low_halves_duplicates_are_finished(ctx):
+    """Buckets the counting leaf does not take (a key with more copies than a 16-bit counter holds, a crowded 256-value
+    group) are written out as whole keys and finished by the general leaves."""
+    import torch
+    rng = np.random.default_rng(41)
+    nsrc, nb = 4, 6
+    counts = np.full((nsrc, nb), 30000, dtype=np.int64)
+    base, gaps = [0] * nsrc, [1, 0, 3, 2]
+    src, allk = _rebuild(None, counts, base, gaps, 0, 16, rng)
+    def bucket_slice(x, j):
+        a = base[x] + int(counts[x, :j].sum())
+        return slice(a, a + int(counts[x, j]))
+    for x in range(nsrc):
+        src[bucket_slice(x, 2)] = np.uint32((2 << 16) | 77)           # bucket 2: one key, 120000 copies
+        src[bucket_slice(x, 4)] &= np.uint32(0xFFFF00FF)              # bucket 4: all keys in one 256-value group
+    allk = np.concatenate([src[base[x]:base[x] + int(counts[x].sum())] for x in range(nsrc)])
+    n = int(counts.sum())
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    s16, base16 = _low16_arrivals(src, counts, base)
+    ctx.merge_buckets(torch.from_numpy(s16.view(np.int16)).cuda(), torch.from_numpy(counts).cuda(), base16, 16, 0, dst, n)
+    assert (host(dst, np.uint32) == np.sort(allk)).all()
+    assert ctx.stats().get("merge_rejected", 0) == 2
+
+
 def test_merge_buckets_rejections_are_finished(ctx):
     """Buckets the leaf does not take -- longer than it holds, more than 255 copies of one key -- go through the
     general leaves and still come out sorted."""

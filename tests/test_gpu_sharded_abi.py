@@ -102,7 +102,7 @@ def test_bad_arguments(ctx, comm1):
     sh.close()
 
 
-@pytest.mark.parametrize("scheme", ["fine", "coarse"])
+@pytest.mark.parametrize("scheme", ["fine", "fine-whole-keys", "coarse"])
 @pytest.mark.parametrize("n", [(1 << 20) + 3, 1 << 24])
 def test_whole_exchange_through_rccl_on_one_rank(ctx, comm1, scheme, n):
     """msd_shard_set_option("force_exchange"): the single rank does NOT take the local shortcut -- top-digit passes,
@@ -114,6 +114,9 @@ def test_whole_exchange_through_rccl_on_one_rank(ctx, comm1, scheme, n):
     from oracle import oracle as O
     sh = MsdShard(ctx, comm1)
     sh.set_option("force_exchange", 1)
+    if scheme == "fine-whole-keys":    # (the default fine exchange moves only the keys' low halves: option "low16")
+        sh.set_option("low16", 0)
+        scheme = "fine"
     k = O.gen_uniform_u32(n, seed=n + len(scheme))
     t = dev(k)
     recv = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")

@@ -109,6 +109,14 @@ for it in range(3):
     c1 = ctx.check(work)
     assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
     rejected = ctx.stats().get("merge_rejected", 0)
+    # ---- the same with only the keys' low halves travelling: pack before the exchange, the leaf reads uint16 extents
+    low = torch.empty(n + 64, dtype=torch.int16, device="cuda")
+    note("fine, low halves: pack", timed(lambda: ctx.pack_low16(a, low)))
+    work.fill_(-1)
+    note("fine, low halves: counting leaf over the arrived extents", timed(lambda: ctx.merge_buckets(low, counts, base, 16, 0, work, n)))
+    c1 = ctx.check(work)
+    assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
+    del low
     if hasattr(L, "msd_debug_stamps") and it == 2:
         stamps = read_stamps()
 
@@ -131,6 +139,10 @@ coarse_post = min(ms["coarse: gather runs bucket-major"] + ms["coarse: segmented
 print(json.dumps({"ranks": G, "keys_per_rank": n, "ms_best_of_3": ms,
                   "fine": {"pre_ms": round(fine_pre, 3), "post_ms": round(fine_post, 3), "local_ms_per_step": round(fine_pre + fine_post, 3),
                            "merge_rejected_buckets": rejected},
+                  "fine_low16": {"pre_ms": round(fine_pre + ms["fine, low halves: pack"], 3),
+                                 "post_ms": ms["fine, low halves: counting leaf over the arrived extents"],
+                                 "local_ms_per_step": round(fine_pre + ms["fine, low halves: pack"] + ms["fine, low halves: counting leaf over the arrived extents"], 3),
+                                 "exchange_bytes_per_key": 2},
                   "coarse": {"pre_ms": ms["coarse: top-digit pass"], "post_ms": round(coarse_post, 3),
                              "local_ms_per_step": round(ms["coarse: top-digit pass"] + coarse_post, 3)},
                   **({"stamps_merge_count_kernel": stamps} if stamps else {})}))
