@@ -94,7 +94,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="headline only (the default c2 run also times c3, c5a, c5b)")
     ap.add_argument("--scheme", choices=["fine", "coarse"], default=None, help="N > 1: force the sharding scheme (dist.use_fine)")
-    ap.add_argument("--whole-keys", action="store_true", help="N > 1, fine scheme: whole keys travel instead of their low halves (A/B; dist.FINE_LOW16)")
+    ap.add_argument("--whole-keys", action="store_true", help="N > 1, fine scheme: whole keys travel (A/B; dist.FINE_LOW16 = dist.FINE_HIST = False)")
+    ap.add_argument("--low-halves", action="store_true", help="N > 1, fine scheme: the keys' low halves travel, never histogram records (A/B; dist.FINE_HIST = False)")
     ap.add_argument("--compute-stream", choices=["pool", "high", "default"], default="high",
                     help="N > 1: the stream the local work runs on: a stream of its own (pool; high = with high priority) or torch's default stream")
     ap.add_argument("--one-rank-exchange", action="store_true",
@@ -357,9 +358,10 @@ def main():
     import torch.distributed as dist
     from inplacemsdradixsort_amd import MsdContext
     from inplacemsdradixsort_amd.dist import ShardedSorter, use_fine
-    if args.whole_keys:
+    if args.whole_keys or args.low_halves:
         import inplacemsdradixsort_amd.dist as _d
-        _d.FINE_LOW16 = False
+        _d.FINE_HIST = False
+        _d.FINE_LOW16 = not args.whole_keys
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -555,9 +557,8 @@ def main():
             xch_bytes = out_view.numel() * out_view.element_size()   # (fine scheme: the keys' low halves, 2 bytes each)
         k_algo = algo_bytes_per_elem(cfg)
         sec = dt / K
-        from inplacemsdradixsort_amd import dist as _dm
-        mg = {"scheme": ("fine (top 16 bits before the exchange, " + ("only the keys' low halves travel, " if _dm.FINE_LOW16 else "") +
-                         "counting leaf over the arrived extents)") if fine else "coarse (top digit before the exchange)",
+        mg = {"scheme": (f"fine (top 16 bits before the exchange, {sorter.last_format} travel, counting leaf over what arrived)"
+                         if fine else "coarse (top digit before the exchange)"),
                  "local_before_exchange_ms": round(max_over_ranks(min(pre_ms)), 3),
                  "local_after_exchange_ms": round(max_over_ranks(min(post_ms)), 3),
                  "exchange_alone_ms": round(max_over_ranks(min(xch_ms)), 3),
@@ -578,7 +579,7 @@ def main():
     headline = "Gkeys/s + achieved HBM GB/s, 2^30 uniform u32 keys, 1/2/4/8 MI355X"
     if multi:
         how = (f", range-partitioned over {N} GPUs by one RCCL all-to-all per step (overlapped with the previous step's local work; "
-               + ("fine scheme: shard ordered by its top 16 bits before the exchange, the keys' low halves travel, one counting pass over the arrived extents after it)" if fine
+               + (f"fine scheme: shard ordered by its top 16 bits before the exchange, {sorter.last_format} travel, one counting pass over what arrived after it)" if fine
                   else (f"the arrived runs are gathered bucket-major and sorted as {256 // N} segments on 24 bits)" if N <= 4
                         else f"the arrived keys are sorted on {32 - N.bit_length() + 1} bits)")))
     else:

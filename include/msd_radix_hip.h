@@ -150,7 +150,17 @@ int msd_gather_runs_u64(msd_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, co
  *     with d_keys; asynchronous); msd_merge_buckets_u32_low16 is msd_merge_buckets_u32 with open_bits = 16 for extents of
  *     such low halves (d_src, src_cap and src_base in uint16 elements) and writes whole keys.  Half the exchange volume --
  *     the exchange is what bounds a step at 2 and 4 GPUs (one xGMI link per pair) -- for one more pass over the shard
- *     (6 bytes per key) before it. */
+ *     (6 bytes per key) before it.
+ *   msd_hist2_pack_u32 / msd_merge_buckets_u32_hist2: dense buckets (2^14 keys and more per source and bucket: 2^30 keys per
+ *     rank) travel as HISTOGRAMS of their low halves instead: per bucket one record of msd_hist2_record_bytes() = 17408
+ *     bytes -- 2^16 2-bit counters (0, 1, 2, "3 or more") + up to 255 (value, copies) entries for the values with three or
+ *     more copies -- whatever the bucket holds; a quarter of the whole keys' bytes at 2^14 keys per bucket.
+ *     msd_hist2_pack_u32 writes the records of buckets 0 .. nbuckets - 1 (d_bounds: nbuckets + 1 boundaries, as from
+ *     msd_bucket_bounds_u32 with shift 16) back to back to d_rec and sets *d_overflow (device; cleared first) if a bucket
+ *     has more than 65535 keys or more than 255 such values -- the caller must then send the low halves themselves.
+ *     Asynchronous.  msd_merge_buckets_u32_hist2: source x's records of this rank's nbuckets buckets lie at
+ *     d_rec + x * nbuckets * 17408; d_counts as above (it gives the buckets' places in d_dst); the sum of the
+ *     histograms of a bucket IS the sorted bucket. */
 int msd_sort_u32_top(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, int end_bit, int begin_bit);
 int msd_sort_u64_top(msd_ctx *ctx, uint64_t *d_keys, uint64_t n, int end_bit, int begin_bit);
 int msd_sort_pairs_u64_top(msd_ctx *ctx, uint64_t *d_keys, uint64_t *d_rids, uint64_t n, int end_bit, int begin_bit);
@@ -160,6 +170,11 @@ int msd_merge_buckets_u32(msd_ctx *ctx, const uint32_t *d_src, uint64_t src_cap,
 			  uint32_t nsrc, uint32_t nbuckets, int open_bits, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap,
 			  uint64_t n_expected);
 int msd_pack_low16_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint16_t *d_out);
+uint64_t msd_hist2_record_bytes(void);
+int msd_hist2_pack_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec,
+		       uint64_t rec_bytes, uint32_t *d_overflow);
+int msd_merge_buckets_u32_hist2(msd_ctx *ctx, const void *d_rec, uint64_t rec_bytes, const uint64_t *d_counts, uint32_t nsrc,
+				uint32_t nbuckets, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected);
 int msd_merge_buckets_u32_low16(msd_ctx *ctx, const uint16_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base,
 				uint32_t nsrc, uint32_t nbuckets, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected);
 

@@ -114,6 +114,12 @@ class MsdContext:
         nsrc, nb = int(counts.shape[0]), int(counts.shape[1])
         if len(src_base) != nsrc:
             raise MsdError("merge_buckets: one base offset per source row")
+        if src.element_size() == 1:   # histogram records (hist2_pack): source x's at x * nb * HIST2_RECORD_BYTES
+            if open_bits != 16:
+                raise MsdError("merge_buckets: histogram records need 16 open bits")
+            self._ok(self._L.msd_merge_buckets_u32_hist2(self._h, self._ptr(src, 1), src.numel(), self._ptr(counts, 8), nsrc, nb,
+                                                         first_prefix, self._ptr(dst, 4), dst.numel(), n_expected))
+            return
         if src.element_size() == 2:   # extents of low halves (pack_low16): the upper half of a key is its bucket's number
             if open_bits != 16:
                 raise MsdError("merge_buckets: extents of low halves need 16 open bits")
@@ -122,6 +128,21 @@ class MsdContext:
             return
         self._ok(self._L.msd_merge_buckets_u32(self._h, self._ptr(src, 4), src.numel(), self._ptr(counts, 8), self._u64arr(src_base),
                                                nsrc, nb, open_bits, first_prefix, self._ptr(dst, 4), dst.numel(), n_expected))
+
+    HIST2_RECORD_BYTES = 17408
+
+    def hist2_pack(self, keys, bounds, rec):
+        """``rec`` (uint8, >= (bounds.numel() - 1) * HIST2_RECORD_BYTES) <- one histogram record per bucket of the u32 ``keys``
+        (ordered by their upper halves; ``bounds`` from :meth:`bucket_bounds` with shift 16).  Returns a one-element int32
+        tensor on the device: non-zero = some bucket does not fit a record (send the low halves instead)."""
+        torch = _torch()
+        nb = bounds.numel() - 1
+        if keys.element_size() != 4 or rec.element_size() != 1 or rec.numel() < nb * self.HIST2_RECORD_BYTES:
+            raise MsdError("hist2_pack: u32 keys, a uint8 buffer of one record per bucket")
+        flag = torch.zeros(1, dtype=torch.int32, device=keys.device)
+        self._ok(self._L.msd_hist2_pack_u32(self._h, self._ptr(keys, 4), keys.numel(), self._ptr(bounds, 8), nb, self._ptr(rec, 1), rec.numel(),
+                                            C.c_void_p(flag.data_ptr())))
+        return flag
 
     def pack_low16(self, keys, out) -> None:
         """``out`` (int16, >= keys.numel() elements) <- the low 16 bits of the u32 ``keys``, in order."""

@@ -395,6 +395,17 @@ constexpr uint64_t kMcMaxKeys = (uint64_t)kMcSeg * (kMcMaxSegs - 1);
 constexpr size_t kMcLds = ((size_t)kMcCwWords + 272 + (kMcTh / 64) * kMcSeg + 16 + 4 + 48 + (kMcMaxSegs + 4) / 2) * 4;
 static_assert(kMcLds <= 160 * 1024, "one workgroup per CU");
 
+// IN = Hist2 (extent mode, 16 open bits): what arrived is not keys at all but, per source and bucket, the HISTOGRAM of the
+// bucket's low halves (hist2_pack_kernel below): 2^16 2-bit counters + the values with three or more copies.  A bucket's
+// keys are the sum of its sources' histograms: every thread adds up its 64 values' fields in registers -- no fetch-adds --
+// and the scan and the output run as for keys.  17 KiB per source and bucket whatever the bucket holds: at 2^14 keys
+// per source and bucket (2^30 keys per rank) a quarter of the whole keys' bytes.
+struct Hist2 { unsigned char b; };
+constexpr uint32_t kH2Fields = 16384;                    // bytes of 2-bit fields: value v = bits 2 (v & 15) of word v >> 4
+constexpr uint32_t kH2MaxExc = 255;                      // values with >= 3 copies a record can name
+constexpr uint32_t kH2Rec = kH2Fields + (kH2MaxExc + 1) * 4; // + [number of entries][value << 16 | copies] ...
+static_assert(kH2Rec % 16 == 0, "records are read and written as 16-byte vectors");
+
 // IN = uint16_t (extent mode, 16 open bits): the extents hold only the keys' LOW halves -- the upper half of a key is its
 // bucket's number, which the receiver of a multi-GPU exchange knows; half the bytes cross the links and half are read here.
 template <bool LIST, typename IN = uint32_t>
@@ -406,9 +417,10 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 	const uint32_t *__restrict__ status)
 {
 	constexpr int TH = kMcTh;
+	constexpr bool HIST = sizeof(IN) == 1;
 	constexpr bool IN16 = sizeof(IN) == 2;
 	constexpr uint32_t VE = 16 / sizeof(IN); // elements per 16-byte vector
-	static_assert(!LIST || !IN16, "a list's segments are sorted where they are: whole keys");
+	static_assert(!LIST || (!IN16 && !HIST), "a list's segments are sorted where they are: whole keys");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem); // 2 x 16-bit counters per word, later offsets inside the value's group
 	uint32_t *gbase = cw + kMcCwWords;                 // 257 group bases
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 			d = rfl64(dst_off[cur]);
 			n64 = rfl64(dst_off[cur + 1]) - d;
 		}
-		const bool bits_ok = bits >= 1 && bits <= 16 && (!IN16 || bits == 16);
+		const bool bits_ok = bits >= 1 && bits <= 16 && ((!IN16 && !HIST) || bits == 16);
 		const uint32_t mask = bits_ok ? (1u << bits) - 1u : 0u;
 		if constexpr (LIST)
 			hi = n64 ? rfl(src[d]) & ~mask : 0u; // (read before anything is written: the sort is in place)
@@ -479,8 +491,9 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 				ext[3 * tid + 2] = cnt32[(size_t)tid * nb + cur];
 			}
 		}
-		// ---- clear the counters, take the next ticket
-		for (uint32_t j = tid; j < kMcCwWords / 4; j += TH) reinterpret_cast<u32x4 *>(cw)[j] = u32x4{ 0u, 0u, 0u, 0u };
+		// ---- clear the counters (histograms: every counter is written below), take the next ticket
+		if constexpr (!HIST)
+			for (uint32_t j = tid; j < kMcCwWords / 4; j += TH) reinterpret_cast<u32x4 *>(cw)[j] = u32x4{ 0u, 0u, 0u, 0u };
 		if (tid == 0) {
 			flags[0] = atomicAdd(ticket, 1u) + gridDim.x;
 			flags[1] = 0;
@@ -495,7 +508,38 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 			continue;
 		}
 		bool ok = take;
-		if (take) {
+		// (source x's record of this bucket)
+		auto record = [&](uint32_t x) -> const unsigned char * {
+			return reinterpret_cast<const unsigned char *>(src) + ((size_t)x * nb + cur) * kH2Rec;
+		};
+		if constexpr (HIST) {
+			// ---- count: thread t owns values [64 t, 64 t + 64) = 16 bytes of every source's fields = 32 counter words
+			uint32_t acc[32];
+#pragma unroll
+			for (int j = 0; j < 32; ++j) acc[j] = 0;
+			for (uint32_t x = 0; x < nx; ++x) {
+				const u32x4 q = *reinterpret_cast<const u32x4 *>(record(x) + 16u * tid);
+				const uint32_t wq[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+				for (int i = 0; i < 4; ++i)
+#pragma unroll
+					for (int pp = 0; pp < 8; ++pp)
+						acc[8 * i + pp] += ((wq[i] >> (4 * pp)) & 3u) | (((wq[i] >> (4 * pp + 2)) & 3u) << 16);
+			}
+			u32x4 *cq0 = reinterpret_cast<u32x4 *>(cw + c16_at(tid * 32u));
+#pragma unroll
+			for (int j = 0; j < 8; ++j) cq0[j] = u32x4{ acc[4 * j + 0], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3] };
+			__syncthreads();
+			// ... and the values with three or more copies: the field says 3, the entry the rest
+			for (uint32_t x = 0; x < nx; ++x) {
+				const uint32_t *ex = reinterpret_cast<const uint32_t *>(record(x) + kH2Fields);
+				const uint32_t ne = min(rfl(ex[0]), kH2MaxExc);
+				if (tid < ne) {
+					const uint32_t e = ex[1u + tid], v = e >> 16, c = e & 0xFFFFu;
+					if (c > 3u) (void)__hip_atomic_fetch_add(&cw[c16_at(v >> 1)], (c - 3u) << ((v & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+		} else if (take) {
 			auto count = [&](uint32_t key) {
 				const uint32_t v = key & mask;
 				(void)__hip_atomic_fetch_add(&cw[c16_at(v >> 1)], 1u << ((v & 1u) << 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -720,7 +764,37 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 			// not taken: the bucket goes to its place as it is (extent after extent; a list's segment stays where it is)
 			// and is queued for the general leaves
 			uint64_t at = d;
-			if constexpr (!LIST) {
+			if constexpr (HIST) {
+				// every source's histogram is written out as that source's keys, in order (the general leaves merge them)
+				for (uint32_t x = 0; x < nx; ++x) {
+					const u32x4 q = *reinterpret_cast<const u32x4 *>(record(x) + 16u * tid);
+					const uint32_t wq[4] = { q.x, q.y, q.z, q.w };
+					const uint32_t *ex = reinterpret_cast<const uint32_t *>(record(x) + kH2Fields);
+					const uint32_t ne = min(rfl(ex[0]), kH2MaxExc);
+					auto copies = [&](uint32_t f) -> uint32_t { // of value 64 tid + f
+						uint32_t c = (wq[f >> 4] >> (2u * (f & 15u))) & 3u;
+						if (c == 3u)
+							for (uint32_t k = 0; k < ne; ++k)
+								if ((ex[1u + k] >> 16) == tid * 64u + f) c = ex[1u + k] & 0xFFFFu;
+						return c;
+					};
+					uint32_t mine = 0;
+					for (uint32_t f = 0; f < 64; ++f) mine += copies(f);
+					const uint32_t inc2 = wave_incl_scan(mine);
+					__syncthreads();
+					if (lane == 63) wtot[w] = inc2;
+					__syncthreads();
+					uint32_t o = inc2 - mine, all2 = 0;
+					for (uint32_t ww = 0; ww < TH / 64; ++ww) {
+						const uint32_t t = wtot[ww];
+						if (ww < w) o += t;
+						all2 += t;
+					}
+					for (uint32_t f = 0; f < 64; ++f)
+						for (uint32_t c = copies(f); c; --c) dst[at + o++] = hi | (tid * 64u + f);
+					at += all2;
+				}
+			} else if constexpr (!LIST) {
 				for (uint32_t x = 0; x < nx; ++x) {
 					uint64_t s;
 					uint32_t len;
@@ -755,6 +829,123 @@ __global__ __launch_bounds__(256) void pack_low16_kernel(const uint32_t *__restr
 		__builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(out) + v);
 	}
 	if (blockIdx.x == 0 && threadIdx.x < (n & 7u)) out[(nv << 3) + threadIdx.x] = (uint16_t)keys[(nv << 3) + threadIdx.x];
+}
+
+// hist2_pack_kernel -- what a rank sends of a bucket in the "histogram" form of the fine exchange: the bucket's keys
+// (contiguous: the shard is ordered by its upper halves; bounds[b] .. bounds[b + 1]) are counted on their low halves in
+// 2^16 byte counters in LDS -- 72 KiB with their padding, so that two workgroups share a CU and one's key loads run under
+// the other's LDS phases --, every thread packs its 128 counters into 2-bit fields (0, 1, 2, "3 or more") and the values
+// with three or more copies are listed behind them.  A bucket of more than 65535 keys, a value with more than 255 copies
+// (its byte counter has spilled into the neighbour: the bytes no longer add up to the bucket's keys) or more than 255 listed values
+// set *overflow: the caller then sends the low halves themselves (every rank learns the flag with the counts).
+// (first version: 2^16 16-bit counters, one 1024-thread workgroup per CU: 2.2 ms per 2^30 keys; this one: see DESIGN.md)
+constexpr int kH2Th = 512;
+constexpr uint32_t kH2Words = 16384 + (16384 >> 5) * 4;   // byte counters, four per word, 4 words of padding per 32
+__device__ __forceinline__ uint32_t h2_at(uint32_t w) { return w + ((w >> 5) << 2); }
+constexpr size_t kH2Lds = ((size_t)kH2Words + (kH2MaxExc + 1) + 8) * 4;
+static_assert(2 * kH2Lds <= 160 * 1024, "two workgroups per CU");
+__global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ bounds, uint32_t nb,
+	unsigned char *__restrict__ rec, uint32_t *__restrict__ overflow)
+{
+	constexpr int TH = kH2Th;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t *cw = reinterpret_cast<uint32_t *>(smem); // byte counters (h2_at)
+	uint32_t *exc = cw + kH2Words;                     // [0] entries, then the entries
+	uint32_t *bad = exc + (kH2MaxExc + 1);             // a byte counter has overflowed
+	const uint32_t tid0 = threadIdx.x;
+	auto rfl = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+	for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+		uint32_t tid = tid0;
+		asm volatile("" : "+v"(tid));
+		const uint64_t s0 = bounds[b], s1 = bounds[b + 1];
+		const uint64_t s = (uint64_t)rfl((uint32_t)s0) | ((uint64_t)rfl((uint32_t)(s0 >> 32)) << 32);
+		const uint64_t e = (uint64_t)rfl((uint32_t)s1) | ((uint64_t)rfl((uint32_t)(s1 >> 32)) << 32);
+		const bool fits = e - s <= 65535u;
+		const uint32_t n = fits ? (uint32_t)(e - s) : 0u;
+		for (uint32_t j = tid; j < kH2Words / 4; j += TH) reinterpret_cast<u32x4 *>(cw)[j] = u32x4{ 0u, 0u, 0u, 0u };
+		if (tid < (kH2MaxExc + 1) / 4) reinterpret_cast<u32x4 *>(exc)[tid] = u32x4{ 0u, 0u, 0u, 0u };
+		if (tid == 0) {
+			bad[0] = fits ? 0u : 1u;
+			bad[1] = 0;
+		}
+		__syncthreads();
+		// (fetch-adds without return value; a counter that has spilled into its neighbour shows in the sum of all bytes below)
+		auto count = [&](uint32_t key) {
+			const uint32_t v = key & 0xFFFFu;
+			(void)__hip_atomic_fetch_add(&cw[h2_at(v >> 2)], 1u << ((v & 3u) << 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		};
+		{ // the bucket on the array's 16-byte grid: single elements at both ends, whole vectors between them
+			const uint32_t o = (uint32_t)(s & 3u), tot = n + o, vend = tot >> 2, vfirst = o ? 1u : 0u;
+			const uint32_t *base = keys + (s - o);
+			if (n && tid < 4) {
+				if (o && tid >= o && tid < tot) count(base[tid]);
+				const uint32_t el = (vend << 2) + tid;
+				if (el < tot && (vend > 0 || o == 0)) count(base[el]);
+			}
+			// (eight vectors in flight per thread -- all of a 2^14-key bucket at once; branch-free loads: lanes behind the end
+			// read the last vector again and ignore it)
+			for (uint32_t v0 = vfirst; v0 < vend; v0 += 8 * TH) {
+				u32x4 q[8];
+#pragma unroll
+				for (int u = 0; u < 8; ++u)
+					q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base) + min(v0 + (uint32_t)u * TH + tid, vend - 1u));
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					if (v0 + (uint32_t)u * TH + tid < vend) {
+						count(q[u].x);
+						count(q[u].y);
+						count(q[u].z);
+						count(q[u].w);
+					}
+				}
+			}
+		}
+		__syncthreads();
+		// ---- thread t packs values [128 t, 128 t + 128) = 32 counter words into 32 bytes of fields
+		const u32x4 *cq = reinterpret_cast<const u32x4 *>(cw + h2_at(tid * 32u));
+		uint32_t out[8], bsum = 0;
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			const u32x4 q = cq[j];
+			const uint32_t wq[4] = { q.x, q.y, q.z, q.w };
+			uint32_t o4 = 0;
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				// per byte: min(count, 3) -- 3 where any of the bits 2..7 is set, the low two bits otherwise
+				const uint32_t w = wq[i], hi = w & 0xFCFCFCFCu;
+				bsum += (w & 0x00FF00FFu) + ((w >> 8) & 0x00FF00FFu); // (two 16-bit lanes: 128 bytes of at most 255 fit)
+				const uint32_t nz = ((((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi) & 0x80808080u) >> 7;
+				const uint32_t f = (w & 0x03030303u) | (nz * 3u);
+				o4 |= ((f | (f >> 6) | (f >> 12) | (f >> 18)) & 0xFFu) << (8 * i);
+				if ((f & (f >> 1) & 0x01010101u) != 0u) { // (rare) a value with three or more copies
+					for (uint32_t k2 = 0; k2 < 4; ++k2) {
+						const uint32_t c = (w >> (8 * k2)) & 0xFFu;
+						if (c >= 3u) {
+							const uint32_t k = atomicAdd(&exc[0], 1u);
+							if (k < kH2MaxExc) exc[1u + k] = ((tid * 128u + 16u * j + 4u * i + k2) << 16) | c;
+						}
+					}
+				}
+			}
+			out[j] = o4;
+		}
+		{ // the bytes must add up to the bucket's keys: a counter that passed 255 has carried into its neighbour (or out of its word)
+			uint32_t t = (bsum & 0xFFFFu) + (bsum >> 16);
+#pragma unroll
+			for (int o2 = 32; o2 > 0; o2 >>= 1) t += (uint32_t)__shfl_xor((int)t, o2);
+			if ((tid & 63u) == 0) atomicAdd(&bad[1], t);
+		}
+		unsigned char *r = rec + (size_t)b * kH2Rec;
+		__builtin_nontemporal_store(u32x4{ out[0], out[1], out[2], out[3] }, reinterpret_cast<u32x4 *>(r) + 2 * tid);
+		__builtin_nontemporal_store(u32x4{ out[4], out[5], out[6], out[7] }, reinterpret_cast<u32x4 *>(r) + 2 * tid + 1);
+		__syncthreads();
+		if (tid < (kH2MaxExc + 1) / 4) {
+			const u32x4 q = reinterpret_cast<const u32x4 *>(exc)[tid];
+			if (tid == 0 && (q.x > kH2MaxExc || bad[0] != 0 || bad[1] != n)) atomicOr(overflow, 1u);
+			reinterpret_cast<u32x4 *>(r + kH2Fields)[tid] = q;
+		}
+		__syncthreads();
+	}
 }
 
 // first index i with (keys[i] >> shift) >= first + b, b = 0 .. nbuckets: the boundaries of the buckets of an array that

@@ -1275,6 +1275,10 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false, uint16_t>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false, Hist2>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_pack_kernel),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kH2Lds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<true, uint32_t>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
 		}
@@ -1511,13 +1515,14 @@ template <typename IN>
 static int merge_impl(msd_ctx *c, const IN *src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base, uint32_t nsrc,
 		      uint32_t nb, int open_bits, uint32_t first_prefix, uint32_t *dst, uint64_t dst_cap, uint64_t n_expected)
 {
-	constexpr bool IN16 = sizeof(IN) == 2;
+	constexpr bool IN16 = sizeof(IN) == 2, HIST = sizeof(IN) == 1; // (HIST: src = records of hist2_pack_kernel, src_cap in bytes)
 	if (!c) return MSD_EINVAL;
 	if (!src || !dst || !d_counts || !src_base) return fail(c, MSD_EINVAL, "merge_buckets: null pointer");
 	if (nsrc < 1 || nsrc > 8) return fail(c, MSD_EINVAL, "merge_buckets: 1..8 source runs per bucket");
 	if (nb == 0 || nb > (1u << 24)) return fail(c, MSD_EINVAL, "merge_buckets: bucket count out of range");
 	if (open_bits < 1 || open_bits > 16) return fail(c, MSD_EINVAL, "merge_buckets: 1..16 open bits");
-	if (IN16 && open_bits != 16) return fail(c, MSD_EINVAL, "merge_buckets: extents of low halves need 16 open bits");
+	if ((IN16 || HIST) && open_bits != 16) return fail(c, MSD_EINVAL, "merge_buckets: extents of low halves need 16 open bits");
+	if (HIST && src_cap < (uint64_t)nsrc * nb * kH2Rec) return fail(c, MSD_EINVAL, "merge_buckets: %u x %u records of %u bytes do not fit the source buffer", nsrc, nb, kH2Rec);
 	if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return fail(c, MSD_EINVAL, "merge_buckets: buffers must be 16-byte aligned");
 	if (n_expected > dst_cap) return fail(c, MSD_EINVAL, "merge_buckets: the output buffer is too small");
 	if ((uint64_t)first_prefix + nb > (1ull << (32 - open_bits))) return fail(c, MSD_EINVAL, "merge_buckets: bucket numbers exceed the key's prefix");
@@ -1557,10 +1562,10 @@ static int merge_impl(msd_ctx *c, const IN *src, uint64_t src_cap, const uint64_
 	// ones (2^30 keys per rank: nsrc x 2^14 keys per bucket) merge_count_kernel
 	// (low halves: merge_count_kernel at every bucket size -- shorter buckets cost it more per key, the exchange it follows
 	// cost half)
-	const bool in_regs = !IN16 && (c->merge_leaf == 1 || (c->merge_leaf == 0 && n_expected / nb <= 12000 && open_bits >= (int)kC16MinBits));
-	if constexpr (IN16) {
+	const bool in_regs = !IN16 && !HIST && (c->merge_leaf == 1 || (c->merge_leaf == 0 && n_expected / nb <= 12000 && open_bits >= (int)kC16MinBits));
+	if constexpr (IN16 || HIST) {
 		const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)c->sm_count);
-		hipLaunchKernelGGL((merge_count_kernel<false, uint16_t>), dim3(grid), dim3(kMcTh), kMcLds, c->stream, src, dst, (const uint32_t *)cnt32,
+		hipLaunchKernelGGL((merge_count_kernel<false, IN>), dim3(grid), dim3(kMcTh), kMcLds, c->stream, src, dst, (const uint32_t *)cnt32,
 				   (const uint64_t *)soff, (const uint64_t *)doff, nsrc, nb, (uint32_t)open_bits, first_prefix, (const Segment *)nullptr,
 				   (const uint32_t *)nullptr, rej, &ctr->nslow16, &ctr->count_ticket3, (const uint32_t *)status);
 	} else if (in_regs) {
@@ -1620,6 +1625,32 @@ int msd_merge_buckets_u32_low16(msd_ctx *c, const uint16_t *d_src, uint64_t src_
 				uint32_t nbuckets, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected)
 {
 	return merge_impl<uint16_t>(c, d_src, src_cap, d_counts, src_base, nsrc, nbuckets, 16, first_prefix, d_dst, dst_cap, n_expected);
+}
+int msd_merge_buckets_u32_hist2(msd_ctx *c, const void *d_rec, uint64_t rec_bytes, const uint64_t *d_counts, uint32_t nsrc, uint32_t nbuckets,
+				uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected)
+{
+	const uint64_t zero[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // (records lie at fixed places: source x's at x * nbuckets * record size)
+	return merge_impl<Hist2>(c, (const Hist2 *)d_rec, rec_bytes, d_counts, zero, nsrc, nbuckets, 16, first_prefix, d_dst, dst_cap, n_expected);
+}
+uint64_t msd_hist2_record_bytes(void) { return kH2Rec; }
+int msd_hist2_pack_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec, uint64_t rec_bytes,
+		       uint32_t *d_overflow)
+{
+	if (!c) return MSD_EINVAL;
+	if (!d_keys || !d_bounds || !d_rec || !d_overflow) return fail(c, MSD_EINVAL, "hist2_pack: null pointer");
+	if (nbuckets == 0 || nbuckets > 65536) return fail(c, MSD_EINVAL, "hist2_pack: 1..65536 buckets");
+	if (((uintptr_t)d_keys & 15) || ((uintptr_t)d_rec & 15)) return fail(c, MSD_EINVAL, "hist2_pack: buffers must be 16-byte aligned");
+	if (rec_bytes < (uint64_t)nbuckets * kH2Rec) return fail(c, MSD_EINVAL, "hist2_pack: %u records of %u bytes do not fit the output buffer", nbuckets, kH2Rec);
+	{
+		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * 4, d0 = (uintptr_t)d_rec, d1 = d0 + (uint64_t)nbuckets * kH2Rec;
+		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "hist2_pack: source and destination overlap");
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	HIPCHK(c, hipMemsetAsync(d_overflow, 0, sizeof(uint32_t), c->stream));
+	const unsigned grid = (unsigned)std::min<uint64_t>(nbuckets, (uint64_t)c->sm_count * 2);
+	hipLaunchKernelGGL(hist2_pack_kernel, dim3(grid), dim3(kH2Th), kH2Lds, c->stream, d_keys, d_bounds, nbuckets, (unsigned char *)d_rec, d_overflow);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
 }
 int msd_pack_low16_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, uint16_t *d_out)
 {

@@ -25,6 +25,8 @@ constexpr int kFineBits = 16;                  // the fine scheme orders a shard
 constexpr uint32_t kFineBuckets = 1u << kFineBits;
 constexpr uint64_t kFineMinKeys = 1ull << 27;  // ... when every rank holds at least this many keys
 constexpr uint64_t kMaxPieceBytes = 1ull << 29; // largest single ncclSend / ncclRecv (see all_to_all)
+constexpr uint64_t kHistMinKeys = 3ull << 28;   // the buckets travel as histogram records when every rank holds at least this many keys
+constexpr uint64_t kHistReady = 1ull << 63;     // ... and says so in the top bit of the "keys held" word of its row
 
 } // namespace
 
@@ -38,6 +40,10 @@ struct msd_shard {
 	uint64_t *h_small = nullptr; // pinned
 	bool force_exchange = false; // (tests) a single rank with a communicator goes through the whole exchange instead of sorting locally
 	bool low16 = true;           // fine scheme: only the low halves of the keys are exchanged ("low16" = 0: whole keys; all ranks alike)
+	bool hist = true;            // fine scheme: dense buckets are exchanged as histogram records ("hist" = 0: never; all ranks alike)
+	uint64_t hist_min = 3ull << 28; // ("hist_min_keys": tests)
+	int hist_max_world = 4;         // ("hist_max_world")
+	uint32_t *d_flag = nullptr;
 	std::string err;
 };
 
@@ -79,6 +85,12 @@ __global__ void counts_row_kernel(const uint64_t *__restrict__ bounds, uint32_t 
 	if (b < nb) row[b] = bounds[b + 1] - bounds[b];
 	if (b == nb) row[nb] = cap;
 	if (b == nb + 1) row[nb + 1] = n;
+}
+
+// the row's "keys held" word gets the mark "my buckets are ready as histogram records" unless the packing overflowed
+__global__ void hist_ready_kernel(const uint32_t *__restrict__ overflow, uint64_t *__restrict__ held)
+{
+	if (*overflow == 0) *held |= kHistReady;
 }
 
 // small[src * world + dst] = keys source src holds for destination dst; small[world^2 + r] = capacity of rank r;
@@ -166,7 +178,7 @@ int all_to_all(msd_shard *sh, const T *src, T *dst, const std::vector<uint64_t> 
 {
 	// (16-bit elements travel as twice as many bytes: RCCL has no 16-bit integer type)
 	const ncclDataType_t ty = sizeof(T) == 4 ? ncclUint32 : sizeof(T) == 8 ? ncclUint64 : ncclUint8;
-	const uint64_t per = sizeof(T) == 2 ? 2 : 1; // RCCL elements per element of T
+	const uint64_t per = sizeof(T) == 2 ? 2 : 1; // RCCL elements per element of T (uint8_t: bytes as they are)
 	if (!group_open) SH_NCCL(sh, ncclGroupStart());
 	// RCCL 2.26 (ROCm 7) moves only half of a single send / receive of >= 2 GiB, silently (tools/debug/a2a_big.py: measured on
 	// the GPU box, through torch.distributed and through ncclSend / ncclRecv alike): every pair's block goes in pieces of
@@ -217,12 +229,13 @@ int msd_shard_create(msd_shard **out, msd_ctx *ctx, void *nccl_comm)
 		  hipMalloc((void **)&sh->d_all, W * kRowLen * sizeof(uint64_t)) == hipSuccess &&
 		  hipMalloc((void **)&sh->d_small, (W * W + 2 * W) * sizeof(uint64_t)) == hipSuccess &&
 		  hipMalloc((void **)&sh->d_mine, (size_t)kFineBuckets * sizeof(uint64_t)) == hipSuccess &&
-		  hipMalloc((void **)&sh->d_bounds, ((size_t)kFineBuckets + 1) * sizeof(uint64_t)) == hipSuccess &&
+		  hipMalloc((void **)&sh->d_bounds, ((size_t)kFineBuckets + 3) * sizeof(uint64_t)) == hipSuccess && // (+ the packing's overflow flag)
 		  hipHostMalloc((void **)&sh->h_small, (W * W + 2 * W) * sizeof(uint64_t), hipHostMallocDefault) == hipSuccess;
 	if (!ok) {
 		msd_shard_destroy(sh);
 		return MSD_ENOMEM;
 	}
+	sh->d_flag = reinterpret_cast<uint32_t *>(sh->d_bounds + kFineBuckets + 1);
 	*out = sh;
 	return MSD_OK;
 }
@@ -248,6 +261,18 @@ int msd_shard_set_option(msd_shard *sh, const char *name, int64_t value)
 	}
 	if (!strcmp(name, "low16")) {
 		sh->low16 = value != 0;
+		return MSD_OK;
+	}
+	if (!strcmp(name, "hist")) {
+		sh->hist = value != 0;
+		return MSD_OK;
+	}
+	if (!strcmp(name, "hist_min_keys")) {
+		sh->hist_min = (uint64_t)value;
+		return MSD_OK;
+	}
+	if (!strcmp(name, "hist_max_world")) {
+		sh->hist_max_world = (int)value;
 		return MSD_OK;
 	}
 	return fail(sh, MSD_EINVAL, "unknown option %s", name);
@@ -297,8 +322,36 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 		hipLaunchKernelGGL(counts_row_kernel, dim3((kRowLen + 255) / 256), dim3(256), 0, sh->stream, (const uint64_t *)sh->d_bounds, kFineBuckets,
 				   recv_cap < work_cap ? recv_cap : work_cap, n, sh->d_row);
 		SH_HIP(sh, hipGetLastError());
+		// Dense buckets travel as HISTOGRAMS of their low halves (msd_hist2_pack_u32: one record of 17408 bytes per bucket,
+		// whatever it holds -- a quarter of the whole keys' bytes at 2^14 keys per bucket), packed into the work buffer; a rank
+		// whose packing did not overflow says so in its row, and the records travel only if every rank's did not.
+		const uint64_t rec_total = (uint64_t)kFineBuckets * msd_hist2_record_bytes();
+		// (up to 4 ranks: at 8 a pair's low halves take less time over their link than the local work they hide behind, and
+		// records cost 0.5 ms more to pack -- the figures are in inplacemsdradixsort_amd/dist.py at FINE_HIST_MAX_WORLD)
+		if (sh->hist && W <= sh->hist_max_world && n >= sh->hist_min && work_cap * 4 >= rec_total && recv_cap * 4 >= rec_total) {
+			SH_MSD(sh, msd_hist2_pack_u32(sh->ctx, d_keys, n, sh->d_bounds, kFineBuckets, d_work, work_cap * 4, sh->d_flag));
+			hipLaunchKernelGGL(hist_ready_kernel, dim3(1), dim3(1), 0, sh->stream, (const uint32_t *)sh->d_flag, sh->d_row + kFineBuckets + 1);
+			SH_HIP(sh, hipGetLastError());
+		}
 		int rc = exchange_counts(sh, kFineBuckets, kRowLen, "keys", send_cnt, recv_cnt);
 		if (rc) return rc;
+		bool use_hist = true;
+		for (int r = 0; r < W; ++r) use_hist = use_hist && (sh->h_small[(size_t)W * W + W + r] & kHistReady) != 0;
+		if (use_hist) {
+			std::vector<uint64_t> blocks(W, rec_total / (uint64_t)W);
+			rc = all_to_all<uint8_t>(sh, (const uint8_t *)d_work, (uint8_t *)d_recv, blocks, blocks, false);
+			if (rc) return rc;
+			hipLaunchKernelGGL(mine_kernel, dim3((kFineBuckets + 255) / 256), dim3(256), 0, sh->stream, (const uint64_t *)sh->d_all, kRowLen, per,
+					   (uint32_t)sh->rank, (uint32_t)W, sh->d_mine);
+			SH_HIP(sh, hipGetLastError());
+			uint64_t m = 0;
+			for (int s2 = 0; s2 < W; ++s2) m += recv_cnt[s2];
+			SH_MSD(sh, msd_merge_buckets_u32_hist2(sh->ctx, d_recv, recv_cap * 4, sh->d_mine, (uint32_t)W, per, (uint32_t)sh->rank * per, d_work, work_cap, m));
+			SH_HIP(sh, hipStreamSynchronize(sh->stream));
+			*d_out = d_work;
+			*n_out = m;
+			return MSD_OK;
+		}
 		// Only the keys' LOW halves travel: the shard is ordered by the upper halves, so the upper half of a key is its bucket's
 		// number, which the receiver knows from the counts.  They are packed into the work buffer (dead until the leaf writes
 		// it) and arrive in the receive buffer as uint16 -- half the bytes over the links (one xGMI link per pair of GPUs: at

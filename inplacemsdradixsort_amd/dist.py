@@ -222,7 +222,7 @@ def use_fine(n_keys: int, world: int, have_work: bool, scheme=None, _force_excha
     return world <= 8 and n_keys >= FINE_MIN_KEYS
 
 
-def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
+def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None, hist_ok=None):
     """The fine scheme's count exchange: ``counts`` = this rank's 2^16 bucket sizes (int64, on the device).  One
     all-gather of 2^16 + 1 int64 per rank; the world x world send matrix and the capacities come to the host in ONE
     small copy, the per-bucket counts stay on the device.  Returns (send_list, recv_list, mine): ``mine`` = int64
@@ -230,14 +230,18 @@ def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
     order.  Raises :class:`ReceiveOverflow` on every rank if any rank's total exceeds its capacity."""
     import torch
     nb = 1 << FINE_BITS
-    row = torch.cat([counts.to(torch.int64), torch.tensor([capacity], dtype=torch.int64, device=counts.device)])
+    # (hist_ok: a one-element tensor on the device, non-zero = this rank has its buckets ready as histogram records; the
+    # records travel only if EVERY rank has -- the verdict is returned as send_l.use_hist)
+    flag = (hist_ok.to(torch.int64).reshape(1) != 0).to(torch.int64) if hist_ok is not None else torch.zeros(1, dtype=torch.int64, device=counts.device)
+    row = torch.cat([counts.to(torch.int64), torch.tensor([capacity], dtype=torch.int64, device=counts.device), flag])
     rows = [torch.empty_like(row) for _ in range(world)]
     dist.all_gather(rows, row, group=group)
-    allc = torch.stack(rows)                                      # [sender, bucket | capacity], on the device
+    allc = torch.stack(rows)                                      # [sender, bucket | capacity | records ready], on the device
     nbl = nb // world
     to_rank = allc[:, :nb].view(world, world, nbl).sum(dim=2)     # [sender, destination]
-    small = torch.cat([to_rank.reshape(-1), allc[:, nb]]).cpu()   # one D2H: world^2 + world numbers
-    to_rank_h, caps = small[:world * world].view(world, world), small[world * world:]
+    small = torch.cat([to_rank.reshape(-1), allc[:, nb], allc[:, nb + 1]]).cpu()   # one D2H: world^2 + 2 world numbers
+    to_rank_h, caps = small[:world * world].view(world, world), small[world * world:world * world + world]
+    all_hist = bool((small[world * world + world:] != 0).all())
     totals = to_rank_h.sum(dim=0)
     over = [(r, int(totals[r]), int(caps[r])) for r in range(world) if int(totals[r]) > int(caps[r])]
     if over:
@@ -248,6 +252,7 @@ def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
     mine = allc[:, me * nbl:(me + 1) * nbl].contiguous()
     send_l = _Splits(to_rank_h[me].tolist())
     send_l.max_block = int(to_rank_h.max())
+    send_l.use_hist = all_hist
     return send_l, to_rank_h[:, me].tolist(), mine
 
 
@@ -259,17 +264,51 @@ def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None):
 FINE_LOW16 = True
 
 
+# Dense buckets travel as HISTOGRAMS of their low halves (engine.hist2_pack): one record of 17408 bytes per source and
+# bucket -- 2^16 2-bit counters + the values with three or more copies -- whatever the bucket holds, a quarter of the
+# whole keys' bytes at 2^14 keys per source and bucket (2^30 keys per rank), and the receiver adds histograms instead of
+# counting keys.  Used when every rank holds at least FINE_HIST_MIN_KEYS keys and no bucket overflows its record (every
+# rank reports that with its counts; otherwise the low halves travel).  (False: never; tests and A/B comparisons)
+FINE_HIST = True
+FINE_HIST_MIN_KEYS = 3 << 28     # 12288 keys per bucket: a record is then 0.7 of the bucket's low halves
+# ... and only up to this many ranks.  One GPU's measurements at 2^30 keys per rank (tools/multigpu_local_work.py): the
+# records cost 1.7 ms to pack where the low halves cost 1.3, so a rank's local work per step is 9.1-10.3 ms with
+# records, 8.6-9.6 with low halves (7.5-8.5 with whole keys), while a pair of GPUs -- ONE xGMI link, about 60 GB/s each
+# way -- exchanges 4 n / G bytes as whole keys, half of that as low halves, 1.06 n / G as records: at 2^30 keys 36 / 18 /
+# 9.5 ms at 2 ranks, 18 / 9 / 4.8 at 4, 9 / 4.5 / 2.4 at 8.  Records where the exchange would otherwise outlast the
+# local work (2 ranks) or run level with it (4), low halves where it hides anyway (8).
+FINE_HIST_MAX_WORLD = 4
+HIST2_RECORD_BYTES = 17408
+
+
+def _bytes_view(buf):
+    import torch
+    return buf.view(torch.uint8)
+
+
+def _hist_splits(world: int):
+    nbytes = ((1 << FINE_BITS) // world) * HIST2_RECORD_BYTES
+    sp = _Splits([nbytes] * world)
+    sp.max_block = nbytes
+    return sp
+
+
 def _as_low16(buf):
     """The int16 view of an int32 buffer (twice the elements)."""
     import torch
     return buf.view(torch.int16)
 
 
-def _fine_counts(engine, keys):
-    """Orders the shard by its top 16 bits and returns its 2^16 bucket sizes (int64, on the device)."""
+def _fine_counts(engine, keys, rec=None, world: int = 1):
+    """Orders the shard by its top 16 bits and returns its 2^16 bucket sizes (int64, on the device) -- and, with a uint8
+    buffer ``rec`` that holds 2^16 records, the flag "the buckets are ready in it as histogram records" (else None)."""
     engine.sort_top(keys, 32 - FINE_BITS)
     b = engine.bucket_bounds(keys, 32 - FINE_BITS, 1 << FINE_BITS)
-    return b[1:] - b[:-1]
+    ok = None
+    if (rec is not None and FINE_HIST and world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS
+            and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES):
+        ok = engine.hist2_pack(keys, b, rec) == 0
+    return b[1:] - b[:-1], ok
 
 
 def _fine_finish(engine, arrived, out, mine, got_l, rank: int, world: int):
@@ -323,8 +362,14 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
         engine.sort_u32(keys)
         return keys
     if use_fine(keys.numel(), world, work is not None, scheme, _force_exchange):
-        send_l, got_l, mine = exchange_fine_counts(dist, _fine_counts(engine, keys), min(recv.numel(), work.numel()), world, group)
+        counts, hist_ok = _fine_counts(engine, keys, _bytes_view(work), world)   # (records, like the low halves below, wait in the work buffer)
+        send_l, got_l, mine = exchange_fine_counts(dist, counts, min(recv.numel(), work.numel()), world, group, hist_ok)
         m = int(sum(got_l))
+        if send_l.use_hist and 4 * recv.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES:
+            sp = _hist_splits(world)
+            r8 = _bytes_view(recv)
+            all_to_all_v(dist, r8[:sum(sp)], _bytes_view(work)[:sum(sp)], list(sp), sp, group)
+            return _fine_finish(engine, r8, work, mine, got_l, _rank(dist, group), world)
         if FINE_LOW16 and 2 * work.numel() >= keys.numel():
             # the low halves are packed into the work buffer (dead until the leaf writes it) and arrive in the receive
             # buffer as int16; the leaf puts the upper halves back
@@ -430,6 +475,8 @@ class ShardedSorter:
         self._pending = []
         self._async = None
         self._send16 = []                 # fine scheme: the packed low halves of the shards whose exchange is in flight
+        self._send8 = []                  # ... or their buckets' histogram records
+        self.last_format = None           # what the last fine exchange moved (reporting)
 
     def _all_to_all(self, out, keys, got_l, send_l):
         # torch.distributed returns Work handles whose wait() orders the current stream after the exchange; stand-ins without
@@ -452,9 +499,27 @@ class ShardedSorter:
         recv = self.recv[self._slot]
         if use_fine(keys.numel(), self.world, bool(self.fine_work), self.scheme, self._force):
             cap = min(recv.numel(), min(w.numel() for w in self.fine_work))
-            send_l, got_l, mine = exchange_fine_counts(self.dist, _fine_counts(self.engine, keys), cap, self.world, self.group)  # raises on all ranks
             slot = self._slot
+            rec = None
+            if (FINE_HIST and self.world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS
+                    and 4 * recv.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES):
+                while len(self._send8) < len(self.recv):
+                    self._send8.append(None)
+                if self._send8[slot] is None:
+                    import torch
+                    self._send8[slot] = torch.empty((1 << FINE_BITS) * HIST2_RECORD_BYTES, dtype=torch.uint8, device=keys.device)
+                rec = self._send8[slot]
+            counts, hist_ok = _fine_counts(self.engine, keys, rec, self.world)
+            send_l, got_l, mine = exchange_fine_counts(self.dist, counts, cap, self.world, self.group, hist_ok)  # raises on all ranks
             self._slot = (self._slot + 1) % len(self.recv)
+            self.last_format = "histogram records" if send_l.use_hist else "low halves" if FINE_LOW16 else "whole keys"
+            if send_l.use_hist:
+                # every rank's buckets are ready as histogram records (module comment at FINE_HIST): equal blocks travel
+                sp = _hist_splits(self.world)
+                r8 = _bytes_view(recv)
+                out = r8[:sum(sp)]
+                self._pending.append((out, self._all_to_all(out, rec[:sum(sp)], list(sp), sp), ("fine", r8, mine, got_l)))
+                return
             if FINE_LOW16:
                 # only the low halves travel (module comment at FINE_LOW16): packed into a send buffer of this sorter -- one
                 # per exchange in flight --, received as int16

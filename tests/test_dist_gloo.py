@@ -55,10 +55,57 @@ class NumpyEngine:
         assert (np.diff(a.astype(np.int64)) >= 0).all()
         return torch.from_numpy(np.searchsorted(a, np.arange(first, first + nbuckets + 1, dtype=np.uint64), side="left").astype(np.int64))
 
+    # histogram records (include/msd_radix_hip.h, msd_hist2_pack_u32): 2^16 2-bit fields + [count][value << 16 | copies] x <= 255
+    REC = 17408
+
+    def hist2_pack(self, keys, bounds, rec):
+        a, b, r = keys.numpy().view(np.uint32), bounds.numpy(), rec.numpy()
+        nb, over = b.size - 1, 0
+        shifts = (2 * np.arange(16, dtype=np.uint32))
+        for j in range(nb):
+            v = a[b[j]:b[j + 1]] & np.uint32(0xFFFF)
+            out = r[j * self.REC:(j + 1) * self.REC]
+            out[:] = 0
+            if v.size > 65535:
+                over = 1
+                continue
+            cnt = np.bincount(v, minlength=65536).astype(np.uint32)
+            words = (np.minimum(cnt, 3).reshape(4096, 16) << shifts).sum(axis=1, dtype=np.uint32)
+            out[:16384] = words.view(np.uint8)
+            big = np.flatnonzero(cnt >= 3)
+            ent = out[16384:].view(np.uint32)
+            ent[0] = big.size
+            if big.size > 255:
+                over = 1
+                big = big[:255]
+            ent[1:1 + big.size] = (big.astype(np.uint32) << np.uint32(16)) | cnt[big]
+        return torch.tensor([over], dtype=torch.int32)
+
+    def _hist2_counts(self, r):
+        """the copies of every value a record stands for"""
+        shifts = (2 * np.arange(16, dtype=np.uint32))
+        cnt = ((r[:16384].view(np.uint32)[:, None] >> shifts) & np.uint32(3)).reshape(65536).astype(np.int64)
+        ent = r[16384:].view(np.uint32)
+        for e in ent[1:1 + min(int(ent[0]), 255)]:
+            cnt[int(e) >> 16] = int(e) & 0xFFFF
+        return cnt
+
     def pack_low16(self, keys, out):
         out.numpy().view(np.uint16)[:keys.numel()] = keys.numpy().view(np.uint32).astype(np.uint16)
 
     def merge_buckets(self, src, counts, src_base, open_bits, first_prefix, dst, n_expected):
+        if src.element_size() == 1:              # histogram records: source x's at x * nb * REC; their sum is the sorted bucket
+            r, d, c = src.numpy(), dst.numpy().view(np.uint32), counts.numpy()
+            nsrc, nb = c.shape
+            assert open_bits == 16 and int(c.sum()) == n_expected <= d.size
+            at = 0
+            for j in range(nb):
+                cnt = sum(self._hist2_counts(r[(x * nb + j) * self.REC:(x * nb + j + 1) * self.REC]) for x in range(nsrc))
+                assert int(cnt.sum()) == int(c[:, j].sum())
+                k = np.repeat(np.arange(65536, dtype=np.uint32), cnt) | np.uint32((first_prefix + j) << 16)
+                d[at:at + k.size] = k
+                at += k.size
+            return
         low16 = src.element_size() == 2          # extents of low halves: the upper half of a key is its bucket's number
         s_, d, c = src.numpy().view(np.uint16 if low16 else np.uint32), dst.numpy().view(np.uint32), counts.numpy()
         nsrc, nb = c.shape
@@ -206,6 +253,67 @@ def test_exchange_in_pieces_over_gloo(world, kind, how, piece_bytes):
     gen = O.gen_uniform_u32 if kind == "uniform" else O.gen_zipf_u32
     allk = np.concatenate([gen(n, first=r * n) for r in range(world)])
     assert (np.concatenate([res[r] for r in range(world)]) == O.sort_u32(allk)).all()
+
+
+def _hist_worker(rank, world, port, n, q, pipelined, dups):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import inplacemsdradixsort_amd.dist as D
+    from oracle import oracle as O
+    D.FINE_HIST_MIN_KEYS = 0                     # (the product asks for 3 * 2^28 keys per rank)
+    D.A2A_MAX_BYTES = 1 << 28                    # the records of a pair go in several pieces
+    k = O.gen_uniform_u32(n, seed=9, first=rank * n)
+    if dups:                                     # rank 1 holds a bucket with 300 values of three copies each: its record overflows,
+        if rank == 1:                            # EVERY rank must fall back to the low halves
+            k[:900] = (np.uint32(0x12340000) | np.repeat(np.arange(300, dtype=np.uint32), 3))
+    keys = torch.from_numpy(k.view(np.int32).copy())
+    nrec = (65536 * 17408 + 3) // 4
+    recv = [torch.empty(max(nrec, n * world), dtype=torch.int32) for _ in range(2 if pipelined else 1)]
+    work = [torch.empty(max(nrec, n * world), dtype=torch.int32) for _ in range(2 if pipelined else 1)]
+    eng = NumpyEngine()
+    calls = {"hist": 0, "low16": 0}
+    orig = eng.merge_buckets
+
+    def spy(src, *a, **kw):
+        calls["hist" if src.element_size() == 1 else "low16" if src.element_size() == 2 else "keys"] = calls.get("hist" if src.element_size() == 1 else "low16", 0) + 1
+        return orig(src, *a, **kw)
+
+    eng.merge_buckets = spy
+    if pipelined:
+        sorter = D.ShardedSorter(eng, dist, world, recv, work_bufs=work, scheme="fine")
+        sorter.submit(keys)
+        out = sorter.collect()
+    else:
+        out = D.sort_sharded_u32(eng, keys, recv[0], dist, world, work=work[0], scheme="fine")
+    q.put((rank, out.numpy().view(np.uint32).copy(), dict(calls), k))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("pipelined,dups", [(False, False), (True, False), (False, True)])
+def test_histogram_exchange_over_gloo(pipelined, dups):
+    """The fine scheme's histogram form (dist.FINE_HIST): every rank packs its 2^16 buckets into records, equal blocks
+    travel, the receiver sums histograms; a record that overflows on ONE rank sends every rank back to the low halves."""
+    world, n = 2, 150_000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hist_worker, args=(r, world, port, n, q, pipelined, dups)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        r, out, calls, k = q.get(timeout=600)
+        res[r] = (out, calls, k)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    allk = np.concatenate([res[r][2] for r in range(world)])
+    got = np.concatenate([res[r][0] for r in range(world)])
+    assert (got == np.sort(allk)).all()
+    for r in range(world):
+        assert res[r][1].get("hist", 0) == (0 if dups else 1) and res[r][1].get("low16", 0) == (1 if dups else 0), res[r][1]
 
 
 def test_all_to_all_v_rounds_match_one_call():

@@ -253,6 +253,90 @@ def test_merge_low_halves_duplicates_are_finished(ctx):
     assert ctx.stats().get("merge_rejected", 0) == 2
 
 
+def _hist2_sources(ctx, rng, nsrc, nb, first, per_bucket, edit=None):
+    """Per source a shard ordered by its upper halves over buckets first .. first + nb - 1, its histogram records and bucket
+    sizes: (records back to back source-major, counts[nsrc, nb], all keys, overflow flags)."""
+    import torch
+    recs, counts, allk, flags = [], np.zeros((nsrc, nb), dtype=np.int64), [], []
+    for x in range(nsrc):
+        c = rng.poisson(per_bucket, nb).astype(np.int64)
+        pre = np.repeat(np.arange(first, first + nb, dtype=np.uint64), c)
+        keys = ((pre << np.uint64(16)) | rng.integers(0, 1 << 16, int(c.sum()), dtype=np.uint64)).astype(np.uint32)
+        if edit is not None:
+            keys = edit(x, keys)
+            keys = keys[np.argsort(keys >> np.uint32(16), kind="stable")]
+        t = dev(keys)
+        b = ctx.bucket_bounds(t, 16, nb, first)
+        rec = torch.empty(nb * ctx.HIST2_RECORD_BYTES, dtype=torch.uint8, device="cuda")
+        flags.append(int(ctx.hist2_pack(t, b, rec).item()))
+        recs.append(rec)
+        counts[x] = (b[1:] - b[:-1]).cpu().numpy()
+        allk.append(keys)
+    return torch.cat(recs), counts, np.concatenate(allk), flags
+
+
+@pytest.mark.parametrize("nsrc,nb,per_bucket", [(8, 24, 16384), (4, 40, 16384), (2, 64, 16384), (1, 30, 17000), (3, 50, 3), (8, 16, 12000), (5, 33, 1000)])
+def test_hist2_records_sum_to_the_sorted_bucket(ctx, nsrc, nb, per_bucket):
+    """msd_hist2_pack_u32 + msd_merge_buckets_u32_hist2: the histogram form of the fine exchange.  Every source packs its
+    buckets into records; the sum of a bucket's records, written out, is the sort of all its keys."""
+    import torch
+    rng = np.random.default_rng(nsrc * 131 + nb)
+    first = 3 * nb
+    rec, counts, allk, flags = _hist2_sources(ctx, rng, nsrc, nb, first, per_bucket)
+    assert flags == [0] * nsrc
+    n = int(counts.sum())
+    dst = torch.full((n + 5,), -1, dtype=torch.int32, device="cuda")
+    ctx.merge_buckets(rec, torch.from_numpy(counts).cuda(), [0] * nsrc, 16, first, dst, n)
+    out = host(dst, np.uint32)
+    assert (out[:n] == np.sort(allk)).all() and (out[n:] == 0xFFFFFFFF).all()
+
+
+def test_hist2_many_copies_and_overflow(ctx):
+    """Values with three and more copies travel as (value, copies) entries; a 256-value group with more keys in all than a
+    16-bit offset addresses makes the receiver write the sources' histograms out one after the other (finished by the general
+    leaves); more than 255 such values in one bucket, a value with more than 255 copies, or a bucket of more than 65535
+    keys set the sender's overflow flag."""
+    import torch
+    rng = np.random.default_rng(17)
+    nsrc, nb, first = 4, 8, 100
+
+    def edit(x, keys):
+        b = keys >> np.uint32(16)
+        k = keys.copy()
+        sel = np.flatnonzero(b == first + 1)
+        k[sel[:200]] = np.uint32(((first + 1) << 16) | 4242)                 # 200 copies per source: 800 in all
+        sel = np.flatnonzero(b == first + 2)
+        k[sel[:250]] = np.uint32(((first + 2) << 16) | 7)                    # ... and 250 of another (a byte counter holds 255)
+        sel = np.flatnonzero(b == first + 3)
+        k[sel] = (k[sel] & np.uint32(0xFFFF0000)) | ((k[sel] & np.uint32(0xFFFF)) % np.uint32(200))   # bucket 3: 200 values only, 80 copies each
+        keep = k[b != first + 5]                                             # bucket 5: 250 values of ONE 256-value group, 240 copies each
+        crowd = np.uint32((first + 5) << 16) | np.repeat(np.arange(250, dtype=np.uint32), 240)      # per source: 240000 keys in the group in all
+        return np.concatenate([keep, crowd])
+
+    rec, counts, allk, flags = _hist2_sources(ctx, rng, nsrc, nb, first, 16384, edit)
+    assert flags == [0] * nsrc
+    n = int(counts.sum())
+    dst = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.merge_buckets(rec, torch.from_numpy(counts).cuda(), [0] * nsrc, 16, first, dst, n)
+    assert (host(dst, np.uint32) == np.sort(allk)).all()
+    assert ctx.stats().get("merge_rejected", 0) == 1                         # bucket 5: the group's 240000 keys do not fit a 16-bit offset
+    # the sender's limits
+    k = np.sort(rng.integers(0, 1 << 16, 3000, dtype=np.uint32).repeat(3))   # 3000 values with three copies each
+    t = dev(k)
+    b = ctx.bucket_bounds(t, 16, 1, 0)
+    r1 = torch.empty(ctx.HIST2_RECORD_BYTES, dtype=torch.uint8, device="cuda")
+    assert int(ctx.hist2_pack(t, b, r1).item()) != 0
+    k = rng.integers(0, 1 << 16, 70000, dtype=np.uint32)                     # a bucket of 70000 keys
+    t = dev(k)
+    assert int(ctx.hist2_pack(t, ctx.bucket_bounds(t, 16, 1, 0), r1).item()) != 0
+    k = np.concatenate([rng.permutation(30000).astype(np.uint32), np.full(256, 31000, dtype=np.uint32)])   # a value with 256 copies
+    t = dev(k)
+    assert int(ctx.hist2_pack(t, ctx.bucket_bounds(t, 16, 1, 0), r1).item()) != 0
+    k = rng.permutation(60000).astype(np.uint32)                             # 60000 different keys: fits
+    t = dev(k)
+    assert int(ctx.hist2_pack(t, ctx.bucket_bounds(t, 16, 1, 0), r1).item()) == 0
+
+
 def test_merge_buckets_rejections_are_finished(ctx):
     """Buckets the leaf does not take -- longer than it holds, more than 255 copies of one key -- go through the
     general leaves and still come out sorted."""

@@ -102,7 +102,7 @@ def test_bad_arguments(ctx, comm1):
     sh.close()
 
 
-@pytest.mark.parametrize("scheme", ["fine", "fine-whole-keys", "coarse"])
+@pytest.mark.parametrize("scheme", ["fine", "fine-whole-keys", "fine-histograms", "coarse"])
 @pytest.mark.parametrize("n", [(1 << 20) + 3, 1 << 24])
 def test_whole_exchange_through_rccl_on_one_rank(ctx, comm1, scheme, n):
     """msd_shard_set_option("force_exchange"): the single rank does NOT take the local shortcut -- top-digit passes,
@@ -117,10 +117,15 @@ def test_whole_exchange_through_rccl_on_one_rank(ctx, comm1, scheme, n):
     if scheme == "fine-whole-keys":    # (the default fine exchange moves only the keys' low halves: option "low16")
         sh.set_option("low16", 0)
         scheme = "fine"
+    cap = n + 64
+    if scheme == "fine-histograms":    # (2^30 keys per rank: the buckets travel as histogram records; forced here at any size)
+        sh.set_option("hist_min_keys", 0)
+        cap = max(cap, 65536 * 17408 // 4)
+        scheme = "fine"
     k = O.gen_uniform_u32(n, seed=n + len(scheme))
     t = dev(k)
-    recv = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
-    work = torch.full((n + 64,), -1, dtype=torch.int32, device="cuda")
+    recv = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
+    work = torch.full((cap,), -1, dtype=torch.int32, device="cuda")
     out = sh.sort_u32(t, recv, work, scheme=scheme)
     assert out.data_ptr() == (work if scheme == "fine" else recv).data_ptr() and out.numel() == n
     assert (host(out, np.uint32) == O.sort_u32(k)).all()
@@ -138,6 +143,11 @@ def test_whole_exchange_through_rccl_on_one_rank(ctx, comm1, scheme, n):
     from inplacemsdradixsort_amd.dist import ReceiveOverflow
     with pytest.raises(ReceiveOverflow):
         sh.sort_u32(dev(k), recv[: n // 2], work, scheme=scheme)
+    if cap > n + 64:
+        # a bucket that does not fit a record (300 values with three copies each): the low halves travel instead
+        k[:900] = np.uint32(0x12340000) | np.repeat(np.arange(300, dtype=np.uint32), 3)
+        out = sh.sort_u32(dev(k), recv, work, scheme=scheme)
+        assert (host(out, np.uint32) == np.sort(k)).all()
     sh.close()
 
 
@@ -178,6 +188,24 @@ def _nccl_worker(port, q):
                     outs.append(host(sorter.collect(), np.uint32).copy())
             outs.append(host(sorter.collect(), np.uint32).copy())
             res["pipelined " + scheme] = all((outs[s] == O.sort_u32(O.gen_uniform_u32(n, seed=20 + s))).all() for s in range(3))
+        # the histogram form of the fine exchange (2^30 keys per rank in production; forced here), one-shot and pipelined
+        import inplacemsdradixsort_amd.dist as D
+        D.FINE_HIST_MIN_KEYS = 0
+        cap = 65536 * 17408 // 4
+        k = O.gen_uniform_u32(n, seed=11)
+        out = sort_sharded_u32(ctx, dev(k), torch.empty(cap, dtype=torch.int32, device="cuda"), dist, 1,
+                               work=torch.empty(cap, dtype=torch.int32, device="cuda"), scheme="fine", _force_exchange=True)
+        res["oneshot histograms"] = bool((host(out, np.uint32) == O.sort_u32(k)).all()) and ctx.stats().get("merge_rejected", 1) == 0
+        sorter = ShardedSorter(ctx, dist, 1, [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(2)],
+                               work_bufs=[torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(2)], scheme="fine", _force_exchange=True)
+        outs = []
+        for s in range(3):
+            sorter.submit(dev(O.gen_uniform_u32(n, seed=40 + s)))
+            if s:
+                outs.append(host(sorter.collect(), np.uint32).copy())
+        outs.append(host(sorter.collect(), np.uint32).copy())
+        res["pipelined histograms"] = all((outs[s] == O.sort_u32(O.gen_uniform_u32(n, seed=40 + s))).all() for s in range(3)) and len(sorter._send8) == 2
+        D.FINE_HIST_MIN_KEYS = 3 << 28
         # the C entry point on torch's own communicator
         dist.barrier()
         sh = MsdShard(ctx, torch_nccl_comm(0))
@@ -208,4 +236,4 @@ def test_dist_py_over_the_nccl_backend_on_one_rank():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert "exception" not in res, res
-    assert len(res) == 5 and all(res.values()), res
+    assert len(res) == 7 and all(res.values()), res

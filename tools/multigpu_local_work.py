@@ -117,6 +117,28 @@ for it in range(3):
     c1 = ctx.check(work)
     assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
     del low
+    # ---- ... and with the buckets travelling as histogram records: packed from the ordered shard before the exchange, the
+    # leaf sums the G records of a bucket
+    if it == 0:
+        RB = ctx.HIST2_RECORD_BYTES
+        rec_send = torch.empty(65536 * RB, dtype=torch.uint8, device="cuda")
+        rec_recv = torch.empty(G * nbl * RB, dtype=torch.uint8, device="cuda")
+        hk = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.gen_uniform_u32(hk, seed=it)
+    ctx.sort_top(hk, 16)
+    bnd = ctx.bucket_bounds(hk, 16, 65536)
+    flag = [None]
+    note("fine, histograms: pack", timed(lambda: flag.__setitem__(0, ctx.hist2_pack(hk, bnd, rec_send))))
+    assert int(flag[0].item()) == 0
+    for s_ in range(G):   # what rank 0 receives: per source the records of ITS buckets (here: of the arrived extents)
+        part = a[s_ * chunk:(s_ + 1) * chunk]
+        bp = ctx.bucket_bounds(part, 16, nbl)
+        f2 = ctx.hist2_pack(part, bp, rec_recv[s_ * nbl * RB:(s_ + 1) * nbl * RB])
+        assert int(f2.item()) == 0
+    work.fill_(-1)
+    note("fine, histograms: leaf summing the arrived records", timed(lambda: ctx.merge_buckets(rec_recv, counts, [0] * G, 16, 0, work, n)))
+    c1 = ctx.check(work)
+    assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
     if hasattr(L, "msd_debug_stamps") and it == 2:
         stamps = read_stamps()
 
@@ -143,6 +165,10 @@ print(json.dumps({"ranks": G, "keys_per_rank": n, "ms_best_of_3": ms,
                                  "post_ms": ms["fine, low halves: counting leaf over the arrived extents"],
                                  "local_ms_per_step": round(fine_pre + ms["fine, low halves: pack"] + ms["fine, low halves: counting leaf over the arrived extents"], 3),
                                  "exchange_bytes_per_key": 2},
+                  "fine_hist": {"pre_ms": round(fine_pre + ms["fine, histograms: pack"], 3),
+                                "post_ms": ms["fine, histograms: leaf summing the arrived records"],
+                                "local_ms_per_step": round(fine_pre + ms["fine, histograms: pack"] + ms["fine, histograms: leaf summing the arrived records"], 3),
+                                "exchange_bytes_per_key": round(65536 * 17408 / n, 3)},
                   "coarse": {"pre_ms": ms["coarse: top-digit pass"], "post_ms": round(coarse_post, 3),
                              "local_ms_per_step": round(ms["coarse: top-digit pass"] + coarse_post, 3)},
                   **({"stamps_merge_count_kernel": stamps} if stamps else {})}))
