@@ -170,6 +170,12 @@ int msd_merge_buckets_u32(msd_ctx *ctx, const uint32_t *d_src, uint64_t src_cap,
 			  uint32_t nsrc, uint32_t nbuckets, int open_bits, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap,
 			  uint64_t n_expected);
 int msd_pack_low16_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint16_t *d_out);
+/* msd_sort_u32_top(.., 32, 16) + msd_bucket_bounds_u32 + msd_pack_low16_u32 in one go and two passes less: ONE in-place round
+ * on the top 8 bits, exact counts of all 2^16 upper halves (d_counts: 65536 uint64 on the device -- the bucket sizes the
+ * exchange needs), and the low halves scattered OUT OF PLACE, bucket after bucket (bucket b from the sum of d_counts[0 .. b)
+ * on, in any order inside the bucket), into d_out (n uint16, no overlap with d_keys).  d_keys is left ordered by its top 8
+ * bits.  Blocks the calling thread for the in-place round; the rest is asynchronous. */
+int msd_order_low16_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint16_t *d_out, uint64_t *d_counts);
 uint64_t msd_hist2_record_bytes(void);
 int msd_hist2_pack_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec,
 		       uint64_t rec_bytes, uint32_t *d_overflow);

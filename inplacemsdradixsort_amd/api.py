@@ -144,6 +144,17 @@ class MsdContext:
                                             C.c_void_p(flag.data_ptr())))
         return flag
 
+    def order_low16(self, keys, out):
+        """Orders the u32 ``keys`` by their upper halves and writes only their low halves: ``out`` (int16, >= keys.numel())
+        holds bucket after bucket (bucket = upper half), in any order inside a bucket; returns the 2^16 bucket sizes (int64,
+        on the device).  ``keys`` is left ordered by its top 8 bits."""
+        torch = _torch()
+        if keys.element_size() != 4 or out.element_size() != 2 or out.numel() < keys.numel():
+            raise MsdError("order_low16: u32 keys, an int16 buffer at least as long")
+        counts = torch.empty(65536, dtype=torch.int64, device=keys.device)
+        self._ok(self._L.msd_order_low16_u32(self._h, self._ptr(keys, 4), keys.numel(), self._ptr(out, 2), C.c_void_p(counts.data_ptr())))
+        return counts
+
     def pack_low16(self, keys, out) -> None:
         """``out`` (int16, >= keys.numel() elements) <- the low 16 bits of the u32 ``keys``, in order."""
         if keys.element_size() != 4 or out.element_size() != 2 or out.numel() < keys.numel():

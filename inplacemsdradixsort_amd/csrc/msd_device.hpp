@@ -1926,6 +1926,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_walk_kernel(K *__restrict__
 } // namespace msd
 #include "msd_count16.hpp"
 #include "msd_merge16.hpp"
+#include "msd_scatter16.hpp"
 namespace msd {
 
 // ------------------------------------------- counting leaf (keys or tuples)

@@ -1279,6 +1279,8 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_pack_kernel),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kH2Lds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_low16_kernel),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS16Lds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<true, uint32_t>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
 		}
@@ -1649,6 +1651,44 @@ int msd_hist2_pack_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, const uin
 	HIPCHK(c, hipMemsetAsync(d_overflow, 0, sizeof(uint32_t), c->stream));
 	const unsigned grid = (unsigned)std::min<uint64_t>(nbuckets, (uint64_t)c->sm_count * 2);
 	hipLaunchKernelGGL(hist2_pack_kernel, dim3(grid), dim3(kH2Th), kH2Lds, c->stream, d_keys, d_bounds, nbuckets, (unsigned char *)d_rec, d_overflow);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+int msd_order_low16_u32(msd_ctx *c, uint32_t *d_keys, uint64_t n, uint16_t *d_out, uint64_t *d_counts)
+{
+	if (!c) return MSD_EINVAL;
+	if (!d_out || !d_counts || (n && !d_keys)) return fail(c, MSD_EINVAL, "order_low16: null pointer");
+	if (((uintptr_t)d_keys & 15) || ((uintptr_t)d_out & 15)) return fail(c, MSD_EINVAL, "order_low16: buffers must be 16-byte aligned");
+	if (n >= (1ull << 40)) return fail(c, MSD_EINVAL, "order_low16: too many keys");
+	{
+		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * 4, d0 = (uintptr_t)d_out, d1 = d0 + n * 2;
+		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "order_low16: source and destination overlap");
+	}
+	// one in-place round on the top 8 bits (the direct-placement round 0) ...
+	int rc = sort_impl<uint32_t, NoVal>(c, d_keys, nullptr, n, 32, false, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 24u);
+	if (rc) return rc;
+	// ... exact counts of all upper halves, bucket starts, and the low halves scattered to their buckets' places in d_out
+	HIPCHK(c, hipSetDevice(c->device));
+	Bump sz(nullptr), *bp = &sz;
+	uint64_t *pb = nullptr;
+	uint32_t *wg = nullptr;
+	unsigned long long *base = nullptr;
+	auto carve = [&]() {
+		pb = bp->take<uint64_t>(257);
+		wg = bp->take<uint32_t>((size_t)65536 * kS16Chunks);
+		base = bp->take<unsigned long long>((size_t)65536 * kS16Chunks);
+	};
+	carve();
+	rc = slab_reserve(c, sz.off + 4096);
+	if (rc) return rc;
+	Bump real(c->slab);
+	bp = &real;
+	carve();
+	hipLaunchKernelGGL((bucket_bounds_kernel<uint32_t>), dim3(2), dim3(256), 0, c->stream, (const uint32_t *)d_keys, n, 24u, (uint64_t)0, 256u, pb);
+	hipLaunchKernelGGL(hist16_kernel, dim3(256 * kS16Chunks), dim3(kS16Th), 0, c->stream, (const uint32_t *)d_keys, n, (const uint64_t *)pb, wg);
+	hipLaunchKernelGGL(scan16_kernel, dim3(256), dim3(256), 0, c->stream, (const uint32_t *)wg, (const uint64_t *)pb, (unsigned long long *)d_counts, base);
+	hipLaunchKernelGGL(scatter_low16_kernel, dim3(256 * kS16Chunks), dim3(kS16Th), kS16Lds, c->stream, (const uint32_t *)d_keys, n, (const uint64_t *)pb,
+			   (const unsigned long long *)base, d_out);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }

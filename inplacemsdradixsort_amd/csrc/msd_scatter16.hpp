@@ -1,0 +1,201 @@
+// msd_scatter16.hpp -- the second half of "order a shard by its upper halves and keep only the low halves"
+// (msd_order_low16_u32, included by msd_device.hpp): what a rank of the multi-GPU sort sends when the keys' low halves
+// travel.
+//
+// Round 3's first version ordered the shard IN PLACE by its top 16 bits (two direct-placement rounds, 5.45 ms per 2^30
+// keys) and then copied the low halves out (1.27 ms).  But the second round's output is read exactly once more -- by that
+// copy -- and the copy's target is a second buffer anyway: so the second round can be an OUT-OF-PLACE scatter of the low
+// halves straight into that buffer.  No slot grid, no misplaced blocks, no metadata, no block permutation, and 2 instead
+// of 4 bytes written per key:
+//   1. one in-place round on the top 8 bits (msd_sort_u32_top with begin_bit 24: the direct-placement round 0);
+//   2. the 257 boundaries of the top-byte parents (bucket_bounds_kernel: binary searches);
+//   3. hist16_kernel: a workgroup counts the second byte over its sixteenth of a parent (a read-only pass);
+//   4. scan16_kernel (one workgroup per parent): the sizes of all 2^16 buckets -- what the exchange needs -- and where
+//      every workgroup's share of every bucket starts in the output;
+//   5. scatter_low16_kernel: the same workgroup streams the same chunk, collects low halves per bucket in LDS (256 buffers
+//      of 128 values, one fetch-add per key gives the place) and writes whole 128-byte blocks to ITS part of the bucket:
+//      no device-scope atomics, a deterministic result.  The order of the keys inside a bucket is that of the chunks, and
+//      arbitrary inside a chunk (the receiver's counting leaf does not care).
+// The reference does the same thing when it partitions tuples to the nodes' buffers: counted, then scattered through
+// per-partition software write-combining buffers (src/msb_64.c:611-667, `range_partition_to_blocks`).
+#pragma once
+
+namespace msd {
+
+constexpr int kS16Th = 512;         // scatter: threads per workgroup (two workgroups per CU)
+constexpr uint32_t kS16Cap = 128;   // values a bucket's LDS buffer holds: a block of 64 + what one tile can add
+constexpr uint32_t kS16Chunks = 16; // workgroups per top-byte parent
+constexpr uint32_t kS16Tile = kS16Th * 8;
+constexpr size_t kS16Lds = (size_t)256 * kS16Cap * 2 + 256 * 8 + 256 * 4; // rings | places | fill
+static_assert(2 * kS16Lds <= 160 * 1024, "two workgroups per CU");
+
+// chunk j of parent p (the keys whose top byte is p lie in [pb[p], pb[p + 1])): whole 16-byte vectors of the parent's range
+__device__ __forceinline__ void s16_chunk(const uint64_t *__restrict__ pb, uint32_t p, uint32_t j, uint64_t &a, uint64_t &b)
+{
+	auto rfl64 = [](uint64_t x) -> uint64_t {
+		return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32);
+	};
+	const uint64_t ps = rfl64(pb[p]), pe = rfl64(pb[p + 1]);
+	const uint64_t per = ((pe - ps + kS16Chunks - 1) / kS16Chunks + 3) & ~3ull;
+	a = ps + (uint64_t)j * per < pe ? ps + (uint64_t)j * per : pe;
+	b = a + per < pe ? a + per : pe;
+}
+
+// eight keys per thread of the tile that starts at grid element t0: two 16-byte vectors (the array's last vector may be
+// short: element by element); ok = the key belongs to the chunk [a, b)
+__device__ __forceinline__ void s16_load(const uint32_t *__restrict__ keys, uint64_t n, uint64_t t0, uint64_t a, uint64_t b, uint32_t tid,
+	uint32_t (&k)[8], uint32_t &okmask)
+{
+	okmask = 0;
+#pragma unroll
+	for (int u = 0; u < 2; ++u) {
+		const uint64_t e = t0 + ((uint64_t)u * kS16Th + tid) * 4;
+		if (e + 4 <= n && e < b) {
+			const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(keys + e));
+			k[4 * u + 0] = q.x; k[4 * u + 1] = q.y; k[4 * u + 2] = q.z; k[4 * u + 3] = q.w;
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) k[4 * u + i] = e + i < n && e + i < b ? keys[e + i] : 0u;
+		}
+#pragma unroll
+		for (int i = 0; i < 4; ++i) okmask |= (e + i >= a && e + i < b) ? 1u << (4 * u + i) : 0u;
+	}
+}
+
+// wg[(p * 256 + c) * 16 + j] = keys of chunk j of parent p whose second byte is c
+__global__ __launch_bounds__(kS16Th) void hist16_kernel(const uint32_t *__restrict__ keys, uint64_t n, const uint64_t *__restrict__ pb,
+	uint32_t *__restrict__ wg)
+{
+	__shared__ uint32_t h[256];
+	const uint32_t tid = threadIdx.x, p = blockIdx.x / kS16Chunks, j = blockIdx.x % kS16Chunks;
+	uint64_t a, b;
+	s16_chunk(pb, p, j, a, b);
+	if (tid < 256) h[tid] = 0;
+	__syncthreads();
+	const uint64_t va = a & ~3ull;
+	for (uint64_t t0 = va; t0 < b; t0 += 2 * kS16Tile) { // (sixteen keys in flight per thread)
+		uint32_t k0[8], k1[8], m0, m1;
+		s16_load(keys, n, t0, a, b, tid, k0, m0);
+		s16_load(keys, n, t0 + kS16Tile, a, b, tid, k1, m1);
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			if ((m0 >> u) & 1u) atomicAdd(&h[(k0[u] >> 16) & 255u], 1u);
+#pragma unroll
+		for (int u = 0; u < 8; ++u)
+			if ((m1 >> u) & 1u) atomicAdd(&h[(k1[u] >> 16) & 255u], 1u);
+	}
+	__syncthreads();
+	if (tid < 256) wg[((size_t)p * 256u + tid) * kS16Chunks + j] = h[tid];
+}
+
+// per parent (one workgroup, thread c = second byte): counts[p * 256 + c] = the bucket's keys; base[(p * 256 + c) * 16 + j] =
+// where chunk j's share of the bucket starts in the output
+__global__ __launch_bounds__(256) void scan16_kernel(const uint32_t *__restrict__ wg, const uint64_t *__restrict__ pb,
+	unsigned long long *__restrict__ counts, unsigned long long *__restrict__ base)
+{
+	__shared__ unsigned long long wsum[4];
+	const uint32_t p = blockIdx.x, c = threadIdx.x, lane = c & 63u, w = c >> 6;
+	uint32_t part[kS16Chunks];
+	unsigned long long mine = 0;
+#pragma unroll
+	for (uint32_t j = 0; j < kS16Chunks; ++j) {
+		part[j] = wg[((size_t)p * 256u + c) * kS16Chunks + j];
+		mine += part[j];
+	}
+	counts[p * 256u + c] = mine;
+	const unsigned long long inc = wave_incl_scan64(mine);
+	if (lane == 63) wsum[w] = inc;
+	__syncthreads();
+	unsigned long long at = pb[p] + inc - mine;
+	for (uint32_t ww = 0; ww < w; ++ww) at += wsum[ww];
+#pragma unroll
+	for (uint32_t j = 0; j < kS16Chunks; ++j) {
+		base[((size_t)p * 256u + c) * kS16Chunks + j] = at;
+		at += part[j];
+	}
+}
+
+__global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t *__restrict__ keys, uint64_t n, const uint64_t *__restrict__ pb,
+	const unsigned long long *__restrict__ base, uint16_t *__restrict__ out)
+{
+	constexpr int TH = kS16Th;
+	constexpr uint32_t CAP = kS16Cap;
+	static_assert(CAP == 128 && kS16Th == 512, "a bucket's buffer is two halves of 64 values; a wave looks after 32 buckets");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint16_t *buf = reinterpret_cast<uint16_t *>(smem);                                        // 256 rings of CAP values
+	unsigned long long *dstp = reinterpret_cast<unsigned long long *>(smem + (size_t)256 * CAP * 2); // where a bucket's next values go
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(dstp + 256);                                  // per bucket: values in the ring | first half-ring << 16
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+	const uint32_t p = blockIdx.x / kS16Chunks, j = blockIdx.x % kS16Chunks;
+	uint64_t a, b;
+	s16_chunk(pb, p, j, a, b);
+	if (a >= b) return;
+	if (tid < 256) {
+		cnt[tid] = 0;
+		dstp[tid] = base[((size_t)p * 256u + tid) * kS16Chunks + j];
+	}
+	__syncthreads();
+	const uint64_t va = a & ~3ull; // the chunk on the array's 16-byte grid
+	uint32_t k[8], okm;
+	s16_load(keys, n, va, a, b, tid, k, okm);
+	// a wave looks after buckets 32 w .. 32 w + 31: lane l after the first (l < 32) or second (l >= 32) unwritten half-ring
+	// of bucket 32 w + (l & 31)
+	const uint32_t myc = 32u * w + (lane & 31u), myhalf = lane >> 5;
+	for (uint64_t t0 = va; t0 < b; t0 += kS16Tile) {
+		uint32_t got[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) got[u] = atomicAdd(&cnt[(k[u] >> 16) & 255u], (okm >> u) & 1u); // (a key of another chunk adds nothing)
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			if ((okm >> u) & 1u) {
+				const uint32_t c = (k[u] >> 16) & 255u, in_ring = got[u] & 0xFFFFu, first = got[u] >> 16;
+				if (in_ring < CAP)
+					buf[c * CAP + ((64u * first + in_ring) & (CAP - 1u))] = (uint16_t)k[u];
+				else { // (its ring is full -- a bucket that takes more than 64 of a tile's keys, tile after tile: one by one, to a
+					// place of this chunk's own claimed in LDS)
+					const unsigned long long g = atomicAdd(&dstp[c], 1ull);
+					out[g] = (uint16_t)k[u];
+				}
+			}
+		}
+		// the next tile's keys are on their way while this one's blocks are written
+		uint32_t kn[8], okn;
+		s16_load(keys, n, t0 + kS16Tile, a, b, tid, kn, okn);
+		__syncthreads();
+		{
+			// (keys that found the ring full took numbers beyond it: given back)
+			const uint32_t cc = cnt[myc], first = cc >> 16, have = min(cc & 0xFFFFu, CAP), full = have >> 6; // whole half-rings: 0, 1 or 2
+			const unsigned long long g0 = dstp[myc];
+			unsigned long long jobs = __ballot(myhalf < full);
+			while (jobs) { // one half-ring = 64 values = 128 bytes per step, all lanes
+				const int l = __builtin_ctzll(jobs);
+				jobs &= jobs - 1;
+				const uint32_t c = 32u * w + ((uint32_t)l & 31u), hf = (uint32_t)l >> 5;
+				const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)first, l);
+				const unsigned long long g = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)g0, l) |
+							      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(g0 >> 32), l) << 32)) + 64u * hf;
+				const uint16_t *src = buf + c * CAP + 64u * ((f0 + hf) & 1u);
+				if ((g & 1u) == 0) {
+					if (lane < 32) reinterpret_cast<uint32_t *>(out + g)[lane] = reinterpret_cast<const uint32_t *>(src)[lane];
+				} else
+					out[g + lane] = src[lane];
+			}
+			if (myhalf == 0) {
+				cnt[myc] = (have - 64u * full) | (((first + full) & 1u) << 16);
+				if (full) dstp[myc] = g0 + 64u * full;
+			}
+		}
+		__syncthreads();
+#pragma unroll
+		for (int u = 0; u < 8; ++u) k[u] = kn[u];
+		okm = okn;
+	}
+	// ---- what is left: less than a half-ring per bucket
+	for (uint32_t c = 32u * w; c < 32u * w + 32u; ++c) {
+		const uint32_t cc = cnt[c], rem = cc & 0xFFFFu, first = cc >> 16; // (rem < 64)
+		const unsigned long long g = dstp[c];
+		if (lane < rem) out[g + lane] = buf[c * CAP + 64u * first + lane];
+	}
+}
+
+} // namespace msd

@@ -205,6 +205,43 @@ def test_pack_low16(ctx, n):
     assert (got[:n] == (k & np.uint32(0xFFFF)).astype(np.uint16)).all() and (got[n:] == 0xFFFF).all()
 
 
+def _check_order_low16(ctx, k):
+    """out holds, bucket after bucket (bucket = upper half), exactly the low halves of that bucket's keys"""
+    import torch
+    n = k.size
+    t = dev(k)
+    out = torch.full((n + 8,), -1, dtype=torch.int16, device="cuda")
+    counts = ctx.order_low16(t, out).cpu().numpy()
+    want = np.bincount(k >> np.uint32(16), minlength=65536)
+    assert (counts == want).all()
+    got = out.cpu().numpy().view(np.uint16)
+    assert (got[n:] == 0xFFFF).all()                                  # nothing written behind the last bucket
+    # rebuild the keys from (bucket, low half) and compare the sorted multisets
+    rebuilt = (np.repeat(np.arange(65536, dtype=np.uint32), want) << np.uint32(16)) | got[:n].astype(np.uint32)
+    assert (np.sort(rebuilt) == np.sort(k)).all()
+    assert (np.sort(host(t, np.uint32)) == np.sort(k)).all()          # the keys themselves are only reordered ...
+    top = host(t, np.uint32) >> np.uint32(24)
+    assert (np.diff(top.astype(np.int64)) >= 0).all()                 # ... by their top 8 bits
+
+
+@pytest.mark.parametrize("n", [1, 5, 1000, 70_001, (1 << 20) + 3, 1 << 23, (1 << 25) + 77])
+def test_order_low16_uniform(ctx, n):
+    from oracle import oracle as O
+    _check_order_low16(ctx, O.gen_uniform_u32(n, seed=n))
+
+
+def test_order_low16_skewed_and_narrow(ctx):
+    """Zipf keys (one bucket holds a quarter of the keys: its LDS buffer overflows tile after tile), keys with a constant
+    upper half, keys in a handful of top bytes, sorted and reversed keys."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(61)
+    n = (1 << 21) + 11
+    for k in (O.gen_zipf_u32(n, seed=5), (rng.integers(0, 1 << 16, n, dtype=np.uint32) | np.uint32(0xABCD0000)),
+              rng.integers(0, 1 << 26, n, dtype=np.uint32), np.sort(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)),
+              np.sort(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32))[::-1].copy(), np.full(n, 0x12345678, dtype=np.uint32)):
+        _check_order_low16(ctx, k)
+
+
 @pytest.mark.parametrize("nsrc,nb,per_bucket", [
     (8, 24, 131072), (4, 40, 65536), (2, 64, 32768),                   # 2^30 keys per rank: nsrc x 2^14 keys per bucket
     (3, 50, 40000), (8, 300, 3000), (1, 10, 200000), (8, 2000, 5), (5, 6, 700000), (2, 512, 4096), (8, 512, 16384),

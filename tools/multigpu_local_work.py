@@ -117,6 +117,12 @@ for it in range(3):
     c1 = ctx.check(work)
     assert c1[0] == 0 and c1[1:] == c0[1:], (c0, c1)
     del low
+    # ---- ... ordered and packed in one go (msd_order_low16_u32: one in-place round, exact counts, out-of-place scatter)
+    if it == 0:
+        low2 = torch.empty(n + 64, dtype=torch.int16, device="cuda")
+        ok2 = torch.empty(n, dtype=torch.int32, device="cuda")
+    ctx.gen_uniform_u32(ok2, seed=it)
+    note("fine, low halves: order + pack in one go", timed(lambda: ctx.order_low16(ok2, low2)))
     # ---- ... and with the buckets travelling as histogram records: packed from the ordered shard before the exchange, the
     # leaf sums the G records of a bucket
     if it == 0:
@@ -165,6 +171,10 @@ print(json.dumps({"ranks": G, "keys_per_rank": n, "ms_best_of_3": ms,
                                  "post_ms": ms["fine, low halves: counting leaf over the arrived extents"],
                                  "local_ms_per_step": round(fine_pre + ms["fine, low halves: pack"] + ms["fine, low halves: counting leaf over the arrived extents"], 3),
                                  "exchange_bytes_per_key": 2},
+                  "fine_low16_fused": {"pre_ms": ms["fine, low halves: order + pack in one go"],
+                                       "post_ms": ms["fine, low halves: counting leaf over the arrived extents"],
+                                       "local_ms_per_step": round(ms["fine, low halves: order + pack in one go"] + ms["fine, low halves: counting leaf over the arrived extents"], 3),
+                                       "exchange_bytes_per_key": 2},
                   "fine_hist": {"pre_ms": round(fine_pre + ms["fine, histograms: pack"], 3),
                                 "post_ms": ms["fine, histograms: leaf summing the arrived records"],
                                 "local_ms_per_step": round(fine_pre + ms["fine, histograms: pack"] + ms["fine, histograms: leaf summing the arrived records"], 3),
