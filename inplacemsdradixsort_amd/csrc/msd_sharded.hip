@@ -93,6 +93,12 @@ __global__ void hist_ready_kernel(const uint32_t *__restrict__ overflow, uint64_
 	if (*overflow == 0) *held |= kHistReady;
 }
 
+__global__ void row_tail_kernel(uint32_t nb, uint64_t cap, uint64_t n, uint64_t *__restrict__ row)
+{
+	row[nb] = cap;
+	row[nb + 1] = n;
+}
+
 // small[src * world + dst] = keys source src holds for destination dst; small[world^2 + r] = capacity of rank r;
 // small[world^2 + world + r] = keys rank r holds.  One workgroup per (src, dst).
 __global__ __launch_bounds__(256) void send_matrix_kernel(const uint64_t *__restrict__ all, uint32_t row_len, uint32_t nb, uint32_t world,
@@ -317,18 +323,33 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 	if (fine && (!d_work || W > 8)) return fail(sh, MSD_EINVAL, "sort_u32_sharded: the fine scheme needs a work buffer and at most 8 ranks");
 	if (fine) {
 		const uint32_t per = kFineBuckets / (uint32_t)W;
-		SH_MSD(sh, msd_sort_u32_top(sh->ctx, d_keys, n, 32, 32 - kFineBits));
-		SH_MSD(sh, msd_bucket_bounds_u32(sh->ctx, d_keys, n, 32 - kFineBits, 0, kFineBuckets, sh->d_bounds));
-		hipLaunchKernelGGL(counts_row_kernel, dim3((kRowLen + 255) / 256), dim3(256), 0, sh->stream, (const uint64_t *)sh->d_bounds, kFineBuckets,
-				   recv_cap < work_cap ? recv_cap : work_cap, n, sh->d_row);
-		SH_HIP(sh, hipGetLastError());
+		const uint64_t rec_total = (uint64_t)kFineBuckets * msd_hist2_record_bytes();
 		// Dense buckets travel as HISTOGRAMS of their low halves (msd_hist2_pack_u32: one record of 17408 bytes per bucket,
 		// whatever it holds -- a quarter of the whole keys' bytes at 2^14 keys per bucket), packed into the work buffer; a rank
 		// whose packing did not overflow says so in its row, and the records travel only if every rank's did not.
-		const uint64_t rec_total = (uint64_t)kFineBuckets * msd_hist2_record_bytes();
 		// (up to 4 ranks: at 8 a pair's low halves take less time over their link than the local work they hide behind, and
 		// records cost 0.5 ms more to pack -- the figures are in inplacemsdradixsort_amd/dist.py at FINE_HIST_MAX_WORLD)
-		if (sh->hist && W <= sh->hist_max_world && n >= sh->hist_min && work_cap * 4 >= rec_total && recv_cap * 4 >= rec_total) {
+		const bool want_hist = sh->hist && W <= sh->hist_max_world && n >= sh->hist_min && work_cap * 4 >= rec_total && recv_cap * 4 >= rec_total;
+		// Otherwise only the keys' LOW halves travel: once the shard is ordered by the upper halves, the upper half of a key is
+		// its bucket's number, which the receiver knows from the counts -- half the bytes over the links (one xGMI link per
+		// pair of GPUs: at 2^30 keys per rank the exchange of whole keys outlasts a rank's local work at 2 and 4 GPUs) and for
+		// the leaf to read.  msd_order_low16_u32 orders and packs in one go (one in-place round, exact counts, the low halves
+		// scattered into the work buffer -- dead until the leaf writes it).
+		const bool low16 = sh->low16 && work_cap * 2 >= n;
+		bool packed = false;
+		if (!want_hist && low16) {
+			SH_MSD(sh, msd_order_low16_u32(sh->ctx, d_keys, n, (uint16_t *)d_work, sh->d_row)); // (the row's first 2^16 words: the bucket sizes)
+			hipLaunchKernelGGL(row_tail_kernel, dim3(1), dim3(1), 0, sh->stream, kFineBuckets, recv_cap < work_cap ? recv_cap : work_cap, n, sh->d_row);
+			SH_HIP(sh, hipGetLastError());
+			packed = true;
+		} else {
+			SH_MSD(sh, msd_sort_u32_top(sh->ctx, d_keys, n, 32, 32 - kFineBits));
+			SH_MSD(sh, msd_bucket_bounds_u32(sh->ctx, d_keys, n, 32 - kFineBits, 0, kFineBuckets, sh->d_bounds));
+			hipLaunchKernelGGL(counts_row_kernel, dim3((kRowLen + 255) / 256), dim3(256), 0, sh->stream, (const uint64_t *)sh->d_bounds, kFineBuckets,
+					   recv_cap < work_cap ? recv_cap : work_cap, n, sh->d_row);
+			SH_HIP(sh, hipGetLastError());
+		}
+		if (want_hist) {
 			SH_MSD(sh, msd_hist2_pack_u32(sh->ctx, d_keys, n, sh->d_bounds, kFineBuckets, d_work, work_cap * 4, sh->d_flag));
 			hipLaunchKernelGGL(hist_ready_kernel, dim3(1), dim3(1), 0, sh->stream, (const uint32_t *)sh->d_flag, sh->d_row + kFineBuckets + 1);
 			SH_HIP(sh, hipGetLastError());
@@ -352,13 +373,8 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 			*n_out = m;
 			return MSD_OK;
 		}
-		// Only the keys' LOW halves travel: the shard is ordered by the upper halves, so the upper half of a key is its bucket's
-		// number, which the receiver knows from the counts.  They are packed into the work buffer (dead until the leaf writes
-		// it) and arrive in the receive buffer as uint16 -- half the bytes over the links (one xGMI link per pair of GPUs: at
-		// 2^30 keys per rank the exchange of whole keys outlasts a rank's local work at 2 and 4 GPUs) and for the leaf to read.
-		const bool low16 = sh->low16 && work_cap * 2 >= n;
 		if (low16) {
-			SH_MSD(sh, msd_pack_low16_u32(sh->ctx, d_keys, n, (uint16_t *)d_work));
+			if (!packed) SH_MSD(sh, msd_pack_low16_u32(sh->ctx, d_keys, n, (uint16_t *)d_work)); // (the records did not travel after all)
 			rc = all_to_all<uint16_t>(sh, (const uint16_t *)d_work, (uint16_t *)d_recv, send_cnt, recv_cnt, false);
 		} else
 			rc = all_to_all<uint32_t>(sh, d_keys, d_recv, send_cnt, recv_cnt, false);

@@ -299,16 +299,23 @@ def _as_low16(buf):
     return buf.view(torch.int16)
 
 
-def _fine_counts(engine, keys, rec=None, world: int = 1):
-    """Orders the shard by its top 16 bits and returns its 2^16 bucket sizes (int64, on the device) -- and, with a uint8
-    buffer ``rec`` that holds 2^16 records, the flag "the buckets are ready in it as histogram records" (else None)."""
+def _fine_counts(engine, keys, rec=None, world: int = 1, send16=None):
+    """What a rank does before the fine exchange.  Returns (its 2^16 bucket sizes -- int64, on the device --, the flag "my
+    buckets are ready in ``rec`` as histogram records" or None, "the low halves are ready in ``send16``").
+    * histogram records wanted (``rec`` holds 2^16 of them, few ranks, a big shard): the shard is ordered in place by its
+      top 16 bits (``engine.sort_top``) and packed (``engine.hist2_pack``);
+    * else, with an int16 buffer ``send16``: ``engine.order_low16`` -- one in-place round on the top 8 bits, exact counts,
+      the low halves scattered out of place into ``send16``: two passes over the shard less than ordering in place and
+      packing afterwards (5.5 against 6.75 ms per 2^30 keys);
+    * else the shard is ordered in place and whole keys travel."""
+    want_hist = (rec is not None and FINE_HIST and world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS
+                 and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES)
+    if not want_hist and FINE_LOW16 and send16 is not None and send16.numel() >= keys.numel() and hasattr(engine, "order_low16"):
+        return engine.order_low16(keys, send16), None, True
     engine.sort_top(keys, 32 - FINE_BITS)
     b = engine.bucket_bounds(keys, 32 - FINE_BITS, 1 << FINE_BITS)
-    ok = None
-    if (rec is not None and FINE_HIST and world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS
-            and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES):
-        ok = engine.hist2_pack(keys, b, rec) == 0
-    return b[1:] - b[:-1], ok
+    ok = (engine.hist2_pack(keys, b, rec) == 0) if want_hist else None
+    return b[1:] - b[:-1], ok, False
 
 
 def _fine_finish(engine, arrived, out, mine, got_l, rank: int, world: int):
@@ -362,7 +369,9 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
         engine.sort_u32(keys)
         return keys
     if use_fine(keys.numel(), world, work is not None, scheme, _force_exchange):
-        counts, hist_ok = _fine_counts(engine, keys, _bytes_view(work), world)   # (records, like the low halves below, wait in the work buffer)
+        # (records, like the low halves, wait in the work buffer -- dead until the leaf writes it)
+        w16 = _as_low16(work) if FINE_LOW16 and 2 * work.numel() >= keys.numel() else None
+        counts, hist_ok, packed = _fine_counts(engine, keys, _bytes_view(work), world, w16)
         send_l, got_l, mine = exchange_fine_counts(dist, counts, min(recv.numel(), work.numel()), world, group, hist_ok)
         m = int(sum(got_l))
         if send_l.use_hist and 4 * recv.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES:
@@ -370,11 +379,12 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
             r8 = _bytes_view(recv)
             all_to_all_v(dist, r8[:sum(sp)], _bytes_view(work)[:sum(sp)], list(sp), sp, group)
             return _fine_finish(engine, r8, work, mine, got_l, _rank(dist, group), world)
-        if FINE_LOW16 and 2 * work.numel() >= keys.numel():
-            # the low halves are packed into the work buffer (dead until the leaf writes it) and arrive in the receive
-            # buffer as int16; the leaf puts the upper halves back
-            w16, r16 = _as_low16(work), _as_low16(recv)
-            engine.pack_low16(keys, w16)
+        if w16 is not None:
+            # the low halves (packed into the work buffer by now, or packed here from the shard ordered in place) arrive in
+            # the receive buffer as int16; the leaf puts the upper halves back
+            r16 = _as_low16(recv)
+            if not packed:
+                engine.pack_low16(keys, w16)
             all_to_all_v(dist, r16[:m], w16[:keys.numel()], got_l, send_l, group)
             return _fine_finish(engine, r16, work, mine, got_l, _rank(dist, group), world)
         all_to_all_v(dist, recv[:m], keys, got_l, send_l, group)
@@ -509,7 +519,15 @@ class ShardedSorter:
                     import torch
                     self._send8[slot] = torch.empty((1 << FINE_BITS) * HIST2_RECORD_BYTES, dtype=torch.uint8, device=keys.device)
                 rec = self._send8[slot]
-            counts, hist_ok = _fine_counts(self.engine, keys, rec, self.world)
+            send16 = None
+            if FINE_LOW16:   # the low halves of the shards whose exchange is in flight: one send buffer per receive buffer
+                while len(self._send16) < len(self.recv):
+                    self._send16.append(None)
+                if self._send16[slot] is None or self._send16[slot].numel() < keys.numel():
+                    import torch
+                    self._send16[slot] = torch.empty(keys.numel(), dtype=torch.int16, device=keys.device)
+                send16 = self._send16[slot][:keys.numel()]
+            counts, hist_ok, packed = _fine_counts(self.engine, keys, rec, self.world, send16)
             send_l, got_l, mine = exchange_fine_counts(self.dist, counts, cap, self.world, self.group, hist_ok)  # raises on all ranks
             self._slot = (self._slot + 1) % len(self.recv)
             self.last_format = "histogram records" if send_l.use_hist else "low halves" if FINE_LOW16 else "whole keys"
@@ -520,19 +538,13 @@ class ShardedSorter:
                 out = r8[:sum(sp)]
                 self._pending.append((out, self._all_to_all(out, rec[:sum(sp)], list(sp), sp), ("fine", r8, mine, got_l)))
                 return
-            if FINE_LOW16:
-                # only the low halves travel (module comment at FINE_LOW16): packed into a send buffer of this sorter -- one
-                # per exchange in flight --, received as int16
-                while len(self._send16) < len(self.recv):
-                    self._send16.append(None)
-                if self._send16[slot] is None or self._send16[slot].numel() < keys.numel():
-                    import torch
-                    self._send16[slot] = torch.empty(keys.numel(), dtype=torch.int16, device=keys.device)
-                packed = self._send16[slot][:keys.numel()]
-                self.engine.pack_low16(keys, packed)
+            if send16 is not None:
+                # only the low halves travel (module comment at FINE_LOW16), received as int16
+                if not packed:
+                    self.engine.pack_low16(keys, send16)
                 r16 = _as_low16(recv)
                 out = r16[:int(sum(got_l))]
-                self._pending.append((out, self._all_to_all(out, packed, got_l, send_l), ("fine", r16, mine, got_l)))
+                self._pending.append((out, self._all_to_all(out, send16, got_l, send_l), ("fine", r16, mine, got_l)))
                 return
             out = recv[:int(sum(got_l))]
             self._pending.append((out, self._all_to_all(out, keys, got_l, send_l), ("fine", recv, mine, got_l)))

@@ -90,6 +90,14 @@ class NumpyEngine:
             cnt[int(e) >> 16] = int(e) & 0xFFFF
         return cnt
 
+    def order_low16(self, keys, out):
+        a = keys.numpy().view(np.uint32)
+        order = np.argsort(a >> np.uint32(16), kind="stable")
+        out.numpy().view(np.uint16)[:a.size] = a[order].astype(np.uint16)
+        counts = np.bincount(a >> np.uint32(16), minlength=65536).astype(np.int64)
+        a[:] = a[np.argsort(a >> np.uint32(24), kind="stable")]       # (the shard is left ordered by its top 8 bits)
+        return torch.from_numpy(counts)
+
     def pack_low16(self, keys, out):
         out.numpy().view(np.uint16)[:keys.numel()] = keys.numpy().view(np.uint32).astype(np.uint16)
 
