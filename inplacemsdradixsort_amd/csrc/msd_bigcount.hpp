@@ -294,7 +294,7 @@ __global__ __launch_bounds__(1024) void bigcount_scan_kernel(const K *__restrict
 		}
 	}
 	if (w == 15 && lane == 0) {
-		if (run != total) atomicAdd(&ctr->errors, 1u); // every key was counted exactly once
+		if (run != total) msd_note_error(ctr, 13u); // every key was counted exactly once
 		const K mask = (K)nv - 1;
 		seg_hi[si] = keys[sg.start] & ~mask;
 		tv[ntiles] = (uint16_t)(nv - 1u);

@@ -120,7 +120,15 @@ struct Counters { // one per sort call, zeroed per round where noted
 	uint32_t nslow2;         // counting-leaf segments merge_count_kernel (list mode) left to count_walk_kernel
 	uint32_t count_ticket4;  // work ticket of merge_count_kernel (list mode)
 	uint32_t l17_slow;       // leaf17_kernel: segments whose groups took the position-by-position fix-up
+	uint32_t err_sites;      // cumulative: which checks raised `errors` (bit = site, msd_note_error)
+	uint32_t pad_;
 };
+// an internal invariant does not hold: counted, and the place remembered for the error message
+__device__ __forceinline__ void msd_note_error(Counters *ctr, uint32_t site)
+{
+	atomicAdd(&ctr->errors, 1u);
+	atomicOr(&ctr->err_sites, 1u << site);
+}
 static_assert(sizeof(Counters) % 8 == 0, "the words behind the counters are used for 64-bit atomics");
 
 // ---------------------------------------------------------------- diagnostics
@@ -1114,7 +1122,7 @@ __global__ __launch_bounds__(256) void list_prepare_kernel(uint32_t nchildren, C
 	if (ev) {
 		first = atomicAdd(&ctr->nevict, ev);
 		if (first + ev > pool_cap) { // (cannot happen: the pool holds kMinChains + two blocks per child)
-			atomicAdd(&ctr->errors, 1u);
+			msd_note_error(ctr, 0u);
 			ev = 0;
 		}
 	}
@@ -1377,7 +1385,7 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 			}
 			if (retry) {
 			} else if (idx >= len) { // cannot happen when the bookkeeping is right
-				atomicAdd(&ctr->errors, 1u);
+				msd_note_error(ctr, 1u);
 				active = false;
 			} else {
 				tries = 0;
@@ -1391,7 +1399,7 @@ __global__ __launch_bounds__(256) void chains_kernel(ChildArrays ca, const ListE
 				src = e.slot;
 				src_owner = e.owner;
 				if (!slot_ok(src) || !slot_ok(hole)) {
-					atomicAdd(&ctr->errors, 1u);
+					msd_note_error(ctr, 2u);
 					active = false;
 				} else if (!last) { // the next step's list: on its way while this step's blocks move
 					nom = ca.lmeta[src_owner];
@@ -1453,7 +1461,7 @@ __global__ __launch_bounds__(256) void chains_verify_kernel(uint32_t nchildren, 
 	if (ci >= nchildren) return;
 	const uint32_t len = (uint32_t)ca.list_len[ci], hot = ca.flags[ci] >> 8;
 	if (!hot) {
-		if (ca.rpos[(size_t)ci * kRposStride] != len) atomicAdd(&ctr->errors, 1u);
+		if (ca.rpos[(size_t)ci * kRposStride] != len) msd_note_error(ctr, 3u);
 		return;
 	}
 	// sharded cursors: every shard of the chain-continuing entries used up (lanes that found a shard empty have bumped
@@ -1461,9 +1469,9 @@ __global__ __launch_bounds__(256) void chains_verify_kernel(uint32_t nchildren, 
 	const uint32_t nint = ca.n_int[ci];
 	for (uint32_t sh = 0; sh < kHotShards; ++sh) {
 		const uint32_t sb = (uint32_t)((uint64_t)nint * sh / kHotShards), se = (uint32_t)((uint64_t)nint * (sh + 1) / kHotShards);
-		if (ca.hot_cur[(size_t)((hot - 1) * kHotShards + sh) * kRposStride] < se - sb) atomicAdd(&ctr->errors, 1u);
+		if (ca.hot_cur[(size_t)((hot - 1) * kHotShards + sh) * kRposStride] < se - sb) msd_note_error(ctr, 4u);
 	}
-	if (ca.rpos[(size_t)ci * kRposStride] != len - nint) atomicAdd(&ctr->errors, 1u);
+	if (ca.rpos[(size_t)ci * kRposStride] != len - nint) msd_note_error(ctr, 5u);
 }
 
 // ------------------------------------------------------------- C: cleanup
@@ -1601,7 +1609,7 @@ __global__ __launch_bounds__(256) void collect_kernel(const Parent *__restrict__
 	else if (at < small_cap)
 		(which == 0 ? small : small_count)[at] = s;
 	else
-		atomicAdd(&ctr->errors, 1u);
+		msd_note_error(ctr, 6u);
 }
 
 } // namespace msd
@@ -1874,7 +1882,7 @@ __global__ __launch_bounds__(kCountTh, 8) void count_walk_kernel(K *__restrict__
 					fallback[fallback_base + at] = sg;
 				} else {            // ... to the multi-workgroup counting sort (32-bit counters)
 					const uint32_t at = big ? atomicAdd(&ctr->nbig, 1u) : 0xFFFFFFFFu;
-					if (at < big_cap) big[at] = sg; else atomicAdd(&ctr->errors, 1u);
+					if (at < big_cap) big[at] = sg; else msd_note_error(ctr, 7u);
 				}
 			}
 		} else {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__((Direct2Cfg<K, V>::TH), (Direct2Cfg<K, V>::WPE)) vo
 			if constexpr (HV)
 				*reinterpret_cast<uint4 *>(vals + dst) = *reinterpret_cast<const uint4 *>(vbuf + d * B + sub * VEC);
 		} else if (sub == 0)
-			atomicAdd(&ctr->errors, 1u);
+			msd_note_error(ctr, 8u);
 	};
 	// per bucket: a full buffer becomes a block; it takes the next consumed slot of the bucket's own piece
 	// or joins the steal list.  `consumed_now`: the bucket's slot of this tile is in registers by now.
@@ -303,7 +303,7 @@ __global__ __launch_bounds__((Direct2Cfg<K, V>::TH), (Direct2Cfg<K, V>::WPE)) vo
 						*reinterpret_cast<u32x4 *>(keys + dst) = q[u];
 						if constexpr (HV) *reinterpret_cast<u32x4 *>(vals + dst) = qv[u];
 					} else if (ss[u] != NONE && sub == 0)
-						atomicAdd(&ctr->errors, 1u);
+						msd_note_error(ctr, 9u);
 				}
 			}
 		}
@@ -457,7 +457,7 @@ __global__ __launch_bounds__((Direct2Cfg<K, V>::TH), (Direct2Cfg<K, V>::WPE)) vo
 	uint32_t fill_r = 0, lc = 0;
 	if (tid < kP) {
 		fill_r = cnt[tid]; // < B: the last round left no full buffer
-		if (fill_r >= (uint32_t)B) atomicAdd(&ctr->errors, 1u);
+		if (fill_r >= (uint32_t)B) msd_note_error(ctr, 10u);
 		lc = fill_r + hc[tid];
 	}
 	uint32_t ltot;

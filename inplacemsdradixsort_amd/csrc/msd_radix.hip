@@ -692,7 +692,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 						HIPCHK(c, hipMemcpyAsync(c->pinned, ctr, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
 						HIPCHK(c, hipStreamSynchronize(c->stream));
 						memcpy(&hc, c->pinned, sizeof hc);
-						if (hc.errors) return fail(c, MSD_EINTERNAL, "leaf17: %u internal invariant violations", hc.errors);
+						if (hc.errors) return fail(c, MSD_EINTERNAL, "leaf17: %u internal invariant violations (checks 0x%x)", hc.errors, hc.err_sites);
 						add_stat(c, "leaf17_segments", np - hc.nslow2);
 						add_stat(c, "leaf17_slow_segments", hc.l17_slow);
 						cur = rest;
@@ -777,7 +777,7 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 					HIPCHK(c, hipMemcpyAsync((char *)c->pinned + 256, d_next, ahead * sizeof(Segment), hipMemcpyDeviceToHost, c->stream));
 					HIPCHK(c, hipStreamSynchronize(c->stream));
 					memcpy(&hc, c->pinned, sizeof hc);
-					if (hc.errors) return fail(c, MSD_EINTERNAL, "register partition round: %u internal invariant violations", hc.errors);
+					if (hc.errors) return fail(c, MSD_EINTERNAL, "register partition round: %u internal invariant violations (checks 0x%x)", hc.errors, hc.err_sites);
 					nsmall_host = hc.nsmall;
 					ncount_host = hc.ncount;
 					nbig_host = hc.nbig;
@@ -995,7 +995,9 @@ static int sort_impl(msd_ctx *c, K *keys, uint64_t *vals, uint64_t n, int end_bi
 			HIPCHK(c, hipMemcpyAsync((char *)c->pinned + kSegOff - 2 * sizeof(unsigned long long), vres, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
 		HIPCHK(c, hipStreamSynchronize(c->stream));
 		memcpy(&hc, c->pinned, sizeof hc);
-		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations", round, hc.errors);
+		if (hc.errors) return fail(c, MSD_EINTERNAL, "round %d: %u internal invariant violations (checks 0x%x: bit = site of msd_note_error in csrc/; 0 = a scan tile's look-back timed out; "
+									"%u parents, %u stripes, direct placement %s)",
+							     round, hc.errors, hc.err_sites, np, ns, tried_direct ? (hc.direct_uneven ? "declined" : "used") : "not tried");
 		if (hist_checks) {
 			const unsigned long long *h = (const unsigned long long *)((char *)c->pinned + kSegOff - 2 * sizeof(unsigned long long));
 			const uint64_t exact_vary = h[0] ^ h[1];

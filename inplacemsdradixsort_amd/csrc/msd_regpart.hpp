@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kRpTh, 4) void regpart_kernel(uint64_t *__restrict_
 		const uint32_t off = (uint32_t)(start & 1u), tot = n + off; // the parent on the 16-byte grid: elements [off, tot)
 		uint64_t *kb = keys + (start - off), *vb = HV ? vals + (start - off) : nullptr;
 		if (tot > kRpCap || pa.count > kRpCap) { // (the host only sends parents that fit)
-			if (tid == 0) atomicAdd(&ctr->errors, 1u);
+			if (tid == 0) msd_note_error(ctr, 11u);
 			continue;
 		}
 		if (tid < nb) cnt[tid] = 0;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kRpTh, 4) void regpart_kernel(uint64_t *__restrict_
 			if (tid == 0) misc[0] = run;
 		}
 		__syncthreads();
-		if (misc[0] != n && tid == 0) atomicAdd(&ctr->errors, 1u);
+		if (misc[0] != n && tid == 0) msd_note_error(ctr, 12u);
 #pragma unroll
 		for (int u = 0; u < NK; ++u) dr[u] = (dr[u] & 0x80000000u) | (bstart[dr[u] & 0xFFu] + ((dr[u] >> 8) & 0x7FFFFFu) + off);
 		// ---- keys, then payloads: to their places in the staging buffer, out as whole vectors
