@@ -22,10 +22,16 @@
 
 namespace msd {
 
+#ifndef MSD_S16_VEC // (overridable for experiments, tools/variant_run.py)
+#define MSD_S16_VEC 2
+#define MSD_S16_CHUNKS 16
+#endif
 constexpr int kS16Th = 512;         // scatter: threads per workgroup (two workgroups per CU)
 constexpr uint32_t kS16Cap = 128;   // values a bucket's LDS buffer holds: a block of 64 + what one tile can add
-constexpr uint32_t kS16Chunks = 16; // workgroups per top-byte parent
-constexpr uint32_t kS16Tile = kS16Th * 8;
+constexpr uint32_t kS16Chunks = MSD_S16_CHUNKS; // workgroups per top-byte parent
+constexpr int kS16Vec = MSD_S16_VEC;            // 16-byte vectors per thread and tile
+constexpr int kS16Kpt = 4 * kS16Vec;            // keys per thread and tile
+constexpr uint32_t kS16Tile = kS16Th * kS16Kpt;
 constexpr size_t kS16Lds = (size_t)256 * kS16Cap * 2 + 256 * 8 + 256 * 4; // rings | places | fill
 static_assert(2 * kS16Lds <= 160 * 1024, "two workgroups per CU");
 
@@ -41,14 +47,14 @@ __device__ __forceinline__ void s16_chunk(const uint64_t *__restrict__ pb, uint3
 	b = a + per < pe ? a + per : pe;
 }
 
-// eight keys per thread of the tile that starts at grid element t0: two 16-byte vectors (the array's last vector may be
+// a thread's keys of the tile that starts at grid element t0: kS16Vec 16-byte vectors (the array's last vector may be
 // short: element by element); ok = the key belongs to the chunk [a, b)
 __device__ __forceinline__ void s16_load(const uint32_t *__restrict__ keys, uint64_t n, uint64_t t0, uint64_t a, uint64_t b, uint32_t tid,
-	uint32_t (&k)[8], uint32_t &okmask)
+	uint32_t (&k)[kS16Kpt], uint32_t &okmask)
 {
 	okmask = 0;
 #pragma unroll
-	for (int u = 0; u < 2; ++u) {
+	for (int u = 0; u < kS16Vec; ++u) {
 		const uint64_t e = t0 + ((uint64_t)u * kS16Th + tid) * 4;
 		if (e + 4 <= n && e < b) {
 			const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(keys + e));
@@ -74,14 +80,14 @@ __global__ __launch_bounds__(kS16Th) void hist16_kernel(const uint32_t *__restri
 	__syncthreads();
 	const uint64_t va = a & ~3ull;
 	for (uint64_t t0 = va; t0 < b; t0 += 2 * kS16Tile) { // (sixteen keys in flight per thread)
-		uint32_t k0[8], k1[8], m0, m1;
+		uint32_t k0[kS16Kpt], k1[kS16Kpt], m0, m1;
 		s16_load(keys, n, t0, a, b, tid, k0, m0);
 		s16_load(keys, n, t0 + kS16Tile, a, b, tid, k1, m1);
 #pragma unroll
-		for (int u = 0; u < 8; ++u)
+		for (int u = 0; u < kS16Kpt; ++u)
 			if ((m0 >> u) & 1u) atomicAdd(&h[(k0[u] >> 16) & 255u], 1u);
 #pragma unroll
-		for (int u = 0; u < 8; ++u)
+		for (int u = 0; u < kS16Kpt; ++u)
 			if ((m1 >> u) & 1u) atomicAdd(&h[(k1[u] >> 16) & 255u], 1u);
 	}
 	__syncthreads();
@@ -136,17 +142,17 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 	}
 	__syncthreads();
 	const uint64_t va = a & ~3ull; // the chunk on the array's 16-byte grid
-	uint32_t k[8], okm;
+	uint32_t k[kS16Kpt], okm;
 	s16_load(keys, n, va, a, b, tid, k, okm);
 	// a wave looks after buckets 32 w .. 32 w + 31: lane l after the first (l < 32) or second (l >= 32) unwritten half-ring
 	// of bucket 32 w + (l & 31)
 	const uint32_t myc = 32u * w + (lane & 31u), myhalf = lane >> 5;
 	for (uint64_t t0 = va; t0 < b; t0 += kS16Tile) {
-		uint32_t got[8];
+		uint32_t got[kS16Kpt];
 #pragma unroll
-		for (int u = 0; u < 8; ++u) got[u] = atomicAdd(&cnt[(k[u] >> 16) & 255u], (okm >> u) & 1u); // (a key of another chunk adds nothing)
+		for (int u = 0; u < kS16Kpt; ++u) got[u] = atomicAdd(&cnt[(k[u] >> 16) & 255u], (okm >> u) & 1u); // (a key of another chunk adds nothing)
 #pragma unroll
-		for (int u = 0; u < 8; ++u) {
+		for (int u = 0; u < kS16Kpt; ++u) {
 			if ((okm >> u) & 1u) {
 				const uint32_t c = (k[u] >> 16) & 255u, in_ring = got[u] & 0xFFFFu, first = got[u] >> 16;
 				if (in_ring < CAP)
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 			}
 		}
 		// the next tile's keys are on their way while this one's blocks are written
-		uint32_t kn[8], okn;
+		uint32_t kn[kS16Kpt], okn;
 		s16_load(keys, n, t0 + kS16Tile, a, b, tid, kn, okn);
 		__syncthreads();
 		{
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 		}
 		__syncthreads();
 #pragma unroll
-		for (int u = 0; u < 8; ++u) k[u] = kn[u];
+		for (int u = 0; u < kS16Kpt; ++u) k[u] = kn[u];
 		okm = okn;
 	}
 	// ---- what is left: less than a half-ring per bucket
