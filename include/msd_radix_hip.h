@@ -179,6 +179,11 @@ int msd_order_low16_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint16_t *d_
 uint64_t msd_hist2_record_bytes(void);
 int msd_hist2_pack_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec,
 		       uint64_t rec_bytes, uint32_t *d_overflow);
+/* ... from the LOW HALVES msd_order_low16_u32 has written (d_low: n uint16, bucket after bucket; d_bounds from its counts:
+ * msd_bounds_from_counts16 writes the 65537 prefix sums of 65536 counts, asynchronously) -- half the bytes to read. */
+int msd_hist2_pack_u32_low16(msd_ctx *ctx, const uint16_t *d_low, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec,
+			     uint64_t rec_bytes, uint32_t *d_overflow);
+int msd_bounds_from_counts16(msd_ctx *ctx, const uint64_t *d_counts, uint64_t *d_bounds);
 int msd_merge_buckets_u32_hist2(msd_ctx *ctx, const void *d_rec, uint64_t rec_bytes, const uint64_t *d_counts, uint32_t nsrc,
 				uint32_t nbuckets, uint32_t first_prefix, uint32_t *d_dst, uint64_t dst_cap, uint64_t n_expected);
 int msd_merge_buckets_u32_low16(msd_ctx *ctx, const uint16_t *d_src, uint64_t src_cap, const uint64_t *d_counts, const uint64_t *src_base,

@@ -137,12 +137,20 @@ class MsdContext:
         tensor on the device: non-zero = some bucket does not fit a record (send the low halves instead)."""
         torch = _torch()
         nb = bounds.numel() - 1
-        if keys.element_size() != 4 or rec.element_size() != 1 or rec.numel() < nb * self.HIST2_RECORD_BYTES:
-            raise MsdError("hist2_pack: u32 keys, a uint8 buffer of one record per bucket")
+        es = keys.element_size()        # 4: whole keys; 2: the low halves order_low16 has written (half the bytes to read)
+        if es not in (2, 4) or rec.element_size() != 1 or rec.numel() < nb * self.HIST2_RECORD_BYTES:
+            raise MsdError("hist2_pack: u32 keys or their low halves, a uint8 buffer of one record per bucket")
         flag = torch.zeros(1, dtype=torch.int32, device=keys.device)
-        self._ok(self._L.msd_hist2_pack_u32(self._h, self._ptr(keys, 4), keys.numel(), self._ptr(bounds, 8), nb, self._ptr(rec, 1), rec.numel(),
-                                            C.c_void_p(flag.data_ptr())))
+        f = self._L.msd_hist2_pack_u32 if es == 4 else self._L.msd_hist2_pack_u32_low16
+        self._ok(f(self._h, self._ptr(keys, es), keys.numel(), self._ptr(bounds, 8), nb, self._ptr(rec, 1), rec.numel(), C.c_void_p(flag.data_ptr())))
         return flag
+
+    def bounds_from_counts16(self, counts):
+        """int64[65537] on the device: the prefix sums of 65536 bucket sizes."""
+        torch = _torch()
+        out = torch.empty(65537, dtype=torch.int64, device=counts.device)
+        self._ok(self._L.msd_bounds_from_counts16(self._h, self._ptr(counts, 8), C.c_void_p(out.data_ptr())))
+        return out
 
     def order_low16(self, keys, out):
         """Orders the u32 ``keys`` by their upper halves and writes only their low halves: ``out`` (int16, >= keys.numel())

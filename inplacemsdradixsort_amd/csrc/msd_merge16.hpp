@@ -844,10 +844,13 @@ constexpr uint32_t kH2Words = 16384 + (16384 >> 5) * 4;   // byte counters, four
 __device__ __forceinline__ uint32_t h2_at(uint32_t w) { return w + ((w >> 5) << 2); }
 constexpr size_t kH2Lds = ((size_t)kH2Words + (kH2MaxExc + 1) + 8) * 4;
 static_assert(2 * kH2Lds <= 160 * 1024, "two workgroups per CU");
-__global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const uint32_t *__restrict__ keys, const uint64_t *__restrict__ bounds, uint32_t nb,
+// IN = uint16_t: the buckets' LOW HALVES, as msd_order_low16_u32 leaves them (half the bytes to read).
+template <typename IN>
+__global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restrict__ keys, const uint64_t *__restrict__ bounds, uint32_t nb,
 	unsigned char *__restrict__ rec, uint32_t *__restrict__ overflow)
 {
 	constexpr int TH = kH2Th;
+	constexpr uint32_t VE = 16 / sizeof(IN); // values per 16-byte vector
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *cw = reinterpret_cast<uint32_t *>(smem); // byte counters (h2_at)
 	uint32_t *exc = cw + kH2Words;                     // [0] entries, then the entries
@@ -875,27 +878,34 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const uint32_t *__
 			(void)__hip_atomic_fetch_add(&cw[h2_at(v >> 2)], 1u << ((v & 3u) << 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		};
 		{ // the bucket on the array's 16-byte grid: single elements at both ends, whole vectors between them
-			const uint32_t o = (uint32_t)(s & 3u), tot = n + o, vend = tot >> 2, vfirst = o ? 1u : 0u;
-			const uint32_t *base = keys + (s - o);
-			if (n && tid < 4) {
+			const uint32_t o = (uint32_t)(s & (VE - 1u)), tot = n + o, vend = tot / VE, vfirst = o ? 1u : 0u;
+			const IN *base = keys + (s - o);
+			if (n && tid < VE) {
 				if (o && tid >= o && tid < tot) count(base[tid]);
-				const uint32_t el = (vend << 2) + tid;
+				const uint32_t el = vend * VE + tid;
 				if (el < tot && (vend > 0 || o == 0)) count(base[el]);
 			}
 			// (eight vectors in flight per thread -- all of a 2^14-key bucket at once; branch-free loads: lanes behind the end
 			// read the last vector again and ignore it)
-			for (uint32_t v0 = vfirst; v0 < vend; v0 += 8 * TH) {
-				u32x4 q[8];
+			constexpr int U = sizeof(IN) == 2 ? 4 : 8;
+			for (uint32_t v0 = vfirst; v0 < vend; v0 += U * TH) {
+				u32x4 q[U];
 #pragma unroll
-				for (int u = 0; u < 8; ++u)
+				for (int u = 0; u < U; ++u)
 					q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base) + min(v0 + (uint32_t)u * TH + tid, vend - 1u));
 #pragma unroll
-				for (int u = 0; u < 8; ++u) {
+				for (int u = 0; u < U; ++u) {
 					if (v0 + (uint32_t)u * TH + tid < vend) {
 						count(q[u].x);
 						count(q[u].y);
 						count(q[u].z);
 						count(q[u].w);
+						if constexpr (sizeof(IN) == 2) { // (eight low halves per vector; count() masks the value)
+							count(q[u].x >> 16);
+							count(q[u].y >> 16);
+							count(q[u].z >> 16);
+							count(q[u].w >> 16);
+						}
 					}
 				}
 			}

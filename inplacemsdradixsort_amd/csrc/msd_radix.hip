@@ -1279,7 +1279,9 @@ template <typename K, typename V> static int set_lds_attrs(msd_ctx *c)
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&merge_count_kernel<false, Hist2>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMcLds));
-			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_pack_kernel),
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_pack_kernel<uint32_t>),
+						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kH2Lds));
+			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&hist2_pack_kernel<uint16_t>),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kH2Lds));
 			HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_low16_kernel),
 						      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kS16Lds));
@@ -1637,8 +1639,10 @@ int msd_merge_buckets_u32_hist2(msd_ctx *c, const void *d_rec, uint64_t rec_byte
 	return merge_impl<Hist2>(c, (const Hist2 *)d_rec, rec_bytes, d_counts, zero, nsrc, nbuckets, 16, first_prefix, d_dst, dst_cap, n_expected);
 }
 uint64_t msd_hist2_record_bytes(void) { return kH2Rec; }
-int msd_hist2_pack_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec, uint64_t rec_bytes,
-		       uint32_t *d_overflow)
+} // extern "C"
+template <typename IN>
+static int hist2_pack_impl(msd_ctx *c, const IN *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec, uint64_t rec_bytes,
+			   uint32_t *d_overflow)
 {
 	if (!c) return MSD_EINVAL;
 	if (!d_keys || !d_bounds || !d_rec || !d_overflow) return fail(c, MSD_EINVAL, "hist2_pack: null pointer");
@@ -1646,13 +1650,51 @@ int msd_hist2_pack_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, const uin
 	if (((uintptr_t)d_keys & 15) || ((uintptr_t)d_rec & 15)) return fail(c, MSD_EINVAL, "hist2_pack: buffers must be 16-byte aligned");
 	if (rec_bytes < (uint64_t)nbuckets * kH2Rec) return fail(c, MSD_EINVAL, "hist2_pack: %u records of %u bytes do not fit the output buffer", nbuckets, kH2Rec);
 	{
-		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * 4, d0 = (uintptr_t)d_rec, d1 = d0 + (uint64_t)nbuckets * kH2Rec;
+		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * sizeof(IN), d0 = (uintptr_t)d_rec, d1 = d0 + (uint64_t)nbuckets * kH2Rec;
 		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "hist2_pack: source and destination overlap");
 	}
 	HIPCHK(c, hipSetDevice(c->device));
 	HIPCHK(c, hipMemsetAsync(d_overflow, 0, sizeof(uint32_t), c->stream));
 	const unsigned grid = (unsigned)std::min<uint64_t>(nbuckets, (uint64_t)c->sm_count * 2);
-	hipLaunchKernelGGL(hist2_pack_kernel, dim3(grid), dim3(kH2Th), kH2Lds, c->stream, d_keys, d_bounds, nbuckets, (unsigned char *)d_rec, d_overflow);
+	hipLaunchKernelGGL((hist2_pack_kernel<IN>), dim3(grid), dim3(kH2Th), kH2Lds, c->stream, d_keys, d_bounds, nbuckets, (unsigned char *)d_rec, d_overflow);
+	HIPCHK(c, hipGetLastError());
+	return MSD_OK;
+}
+// starts[b] = sum of counts[0 .. b), b = 0 .. 65536 (one workgroup)
+__global__ __launch_bounds__(1024) void bounds16_kernel(const uint64_t *__restrict__ counts, uint64_t *__restrict__ bounds)
+{
+	__shared__ uint64_t wsum[16];
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+	uint64_t mine = 0;
+	for (uint32_t j = 0; j < 64; ++j) mine += counts[tid * 64u + j];
+	const uint64_t inc = wave_incl_scan64(mine);
+	if (lane == 63) wsum[w] = inc;
+	__syncthreads();
+	uint64_t at = inc - mine;
+	for (uint32_t ww = 0; ww < w; ++ww) at += wsum[ww];
+	for (uint32_t j = 0; j < 64; ++j) {
+		bounds[tid * 64u + j] = at;
+		at += counts[tid * 64u + j];
+	}
+	if (tid == 1023) bounds[65536] = at;
+}
+extern "C" {
+int msd_hist2_pack_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec, uint64_t rec_bytes,
+		       uint32_t *d_overflow)
+{
+	return hist2_pack_impl<uint32_t>(c, d_keys, n, d_bounds, nbuckets, d_rec, rec_bytes, d_overflow);
+}
+int msd_hist2_pack_u32_low16(msd_ctx *c, const uint16_t *d_low, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec, uint64_t rec_bytes,
+			     uint32_t *d_overflow)
+{
+	return hist2_pack_impl<uint16_t>(c, d_low, n, d_bounds, nbuckets, d_rec, rec_bytes, d_overflow);
+}
+int msd_bounds_from_counts16(msd_ctx *c, const uint64_t *d_counts, uint64_t *d_bounds)
+{
+	if (!c) return MSD_EINVAL;
+	if (!d_counts || !d_bounds) return fail(c, MSD_EINVAL, "bounds_from_counts16: null pointer");
+	HIPCHK(c, hipSetDevice(c->device));
+	hipLaunchKernelGGL(bounds16_kernel, dim3(1), dim3(1024), 0, c->stream, d_counts, d_bounds);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }

@@ -337,11 +337,19 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 		// scattered into the work buffer -- dead until the leaf writes it).
 		const bool low16 = sh->low16 && work_cap * 2 >= n;
 		bool packed = false;
-		if (!want_hist && low16) {
+		// (records are packed from the low halves, behind them in the work buffer, when both fit)
+		const uint64_t rec_at = (2 * n + 255) / 256 * 256;
+		unsigned char *d_rec = (unsigned char *)d_work;
+		if (low16 && (!want_hist || work_cap * 4 >= rec_at + rec_total)) {
 			SH_MSD(sh, msd_order_low16_u32(sh->ctx, d_keys, n, (uint16_t *)d_work, sh->d_row)); // (the row's first 2^16 words: the bucket sizes)
 			hipLaunchKernelGGL(row_tail_kernel, dim3(1), dim3(1), 0, sh->stream, kFineBuckets, recv_cap < work_cap ? recv_cap : work_cap, n, sh->d_row);
 			SH_HIP(sh, hipGetLastError());
 			packed = true;
+			if (want_hist) {
+				d_rec += rec_at;
+				SH_MSD(sh, msd_bounds_from_counts16(sh->ctx, sh->d_row, sh->d_bounds));
+				SH_MSD(sh, msd_hist2_pack_u32_low16(sh->ctx, (const uint16_t *)d_work, n, sh->d_bounds, kFineBuckets, d_rec, work_cap * 4 - rec_at, sh->d_flag));
+			}
 		} else {
 			SH_MSD(sh, msd_sort_u32_top(sh->ctx, d_keys, n, 32, 32 - kFineBits));
 			SH_MSD(sh, msd_bucket_bounds_u32(sh->ctx, d_keys, n, 32 - kFineBits, 0, kFineBuckets, sh->d_bounds));
@@ -350,7 +358,7 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 			SH_HIP(sh, hipGetLastError());
 		}
 		if (want_hist) {
-			SH_MSD(sh, msd_hist2_pack_u32(sh->ctx, d_keys, n, sh->d_bounds, kFineBuckets, d_work, work_cap * 4, sh->d_flag));
+			if (!packed) SH_MSD(sh, msd_hist2_pack_u32(sh->ctx, d_keys, n, sh->d_bounds, kFineBuckets, d_work, work_cap * 4, sh->d_flag));
 			hipLaunchKernelGGL(hist_ready_kernel, dim3(1), dim3(1), 0, sh->stream, (const uint32_t *)sh->d_flag, sh->d_row + kFineBuckets + 1);
 			SH_HIP(sh, hipGetLastError());
 		}
@@ -360,7 +368,7 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 		for (int r = 0; r < W; ++r) use_hist = use_hist && (sh->h_small[(size_t)W * W + W + r] & kHistReady) != 0;
 		if (use_hist) {
 			std::vector<uint64_t> blocks(W, rec_total / (uint64_t)W);
-			rc = all_to_all<uint8_t>(sh, (const uint8_t *)d_work, (uint8_t *)d_recv, blocks, blocks, false);
+			rc = all_to_all<uint8_t>(sh, (const uint8_t *)d_rec, (uint8_t *)d_recv, blocks, blocks, false);
 			if (rc) return rc;
 			hipLaunchKernelGGL(mine_kernel, dim3((kFineBuckets + 255) / 256), dim3(256), 0, sh->stream, (const uint64_t *)sh->d_all, kRowLen, per,
 					   (uint32_t)sh->rank, (uint32_t)W, sh->d_mine);

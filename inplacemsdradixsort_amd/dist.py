@@ -303,8 +303,9 @@ def _as_low16(buf):
 def _fine_counts(engine, keys, rec=None, world: int = 1, send16=None):
     """What a rank does before the fine exchange.  Returns (its 2^16 bucket sizes -- int64, on the device --, the flag "my
     buckets are ready in ``rec`` as histogram records" or None, "the low halves are ready in ``send16``").
-    * histogram records wanted (``rec`` holds 2^16 of them, few ranks, a big shard): the shard is ordered in place by its
-      top 16 bits (``engine.sort_top``) and packed (``engine.hist2_pack``);
+    * histogram records wanted (``rec`` holds 2^16 of them, few ranks, a big shard): ``engine.order_low16`` as below, then
+      the records are packed from the low halves (``engine.hist2_pack``); without ``send16`` the shard is ordered in place by
+      its top 16 bits (``engine.sort_top``) and the records are packed from the keys;
     * else, with an int16 buffer ``send16``: ``engine.order_low16`` -- one in-place round on the top 8 bits, exact counts,
       the low halves scattered out of place into ``send16``: two passes over the shard less than ordering in place and
       packing afterwards (5.5 against 6.75 ms per 2^30 keys);
@@ -313,6 +314,12 @@ def _fine_counts(engine, keys, rec=None, world: int = 1, send16=None):
                  and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES)
     if not want_hist and FINE_LOW16 and send16 is not None and send16.numel() >= keys.numel() and hasattr(engine, "order_low16"):
         return engine.order_low16(keys, send16), None, True
+    if want_hist and FINE_LOW16 and send16 is not None and send16.numel() >= keys.numel() and hasattr(engine, "order_low16"):
+        # (the records are packed from the low halves order_low16 has written -- which are then also ready for the case that
+        # some rank's records overflow and every rank sends low halves after all)
+        counts = engine.order_low16(keys, send16)
+        ok = engine.hist2_pack(send16[:keys.numel()], engine.bounds_from_counts16(counts), rec) == 0
+        return counts, ok, True
     engine.sort_top(keys, 32 - FINE_BITS)
     b = engine.bucket_bounds(keys, 32 - FINE_BITS, 1 << FINE_BITS)
     ok = (engine.hist2_pack(keys, b, rec) == 0) if want_hist else None
@@ -370,15 +377,21 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
         engine.sort_u32(keys)
         return keys
     if use_fine(keys.numel(), world, work is not None, scheme, _force_exchange):
-        # (records, like the low halves, wait in the work buffer -- dead until the leaf writes it)
-        w16 = _as_low16(work) if FINE_LOW16 and 2 * work.numel() >= keys.numel() else None
-        counts, hist_ok, packed = _fine_counts(engine, keys, _bytes_view(work), world, w16)
+        # (low halves and records wait in the work buffer -- dead until the leaf writes it --, the records behind the low halves)
+        w16 = _as_low16(work)[:keys.numel()] if FINE_LOW16 and 2 * work.numel() >= keys.numel() else None
+        rec_at = (2 * keys.numel() + 255) // 256 * 256 if w16 is not None else 0
+        rec, s16 = _bytes_view(work)[rec_at:], w16
+        if rec.numel() < (1 << FINE_BITS) * HIST2_RECORD_BYTES:   # no room for both: records from the keys, low halves only if needed
+            rec = _bytes_view(work)
+            if FINE_HIST and world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES:
+                s16 = None
+        counts, hist_ok, packed = _fine_counts(engine, keys, rec, world, s16)
         send_l, got_l, mine = exchange_fine_counts(dist, counts, min(recv.numel(), work.numel()), world, group, hist_ok)
         m = int(sum(got_l))
         if send_l.use_hist and 4 * recv.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES:
             sp = _hist_splits(world)
             r8 = _bytes_view(recv)
-            all_to_all_v(dist, r8[:sum(sp)], _bytes_view(work)[:sum(sp)], list(sp), sp, group)
+            all_to_all_v(dist, r8[:sum(sp)], rec[:sum(sp)], list(sp), sp, group)
             return _fine_finish(engine, r8, work, mine, got_l, _rank(dist, group), world)
         if w16 is not None:
             # the low halves (packed into the work buffer by now, or packed here from the shard ordered in place) arrive in
@@ -386,7 +399,7 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
             r16 = _as_low16(recv)
             if not packed:
                 engine.pack_low16(keys, w16)
-            all_to_all_v(dist, r16[:m], w16[:keys.numel()], got_l, send_l, group)
+            all_to_all_v(dist, r16[:m], w16, got_l, send_l, group)
             return _fine_finish(engine, r16, work, mine, got_l, _rank(dist, group), world)
         all_to_all_v(dist, recv[:m], keys, got_l, send_l, group)
         return _fine_finish(engine, recv, work, mine, got_l, _rank(dist, group), world)

@@ -58,12 +58,15 @@ class NumpyEngine:
     # histogram records (include/msd_radix_hip.h, msd_hist2_pack_u32): 2^16 2-bit fields + [count][value << 16 | copies] x <= 255
     REC = 17408
 
+    def bounds_from_counts16(self, counts):
+        return torch.from_numpy(np.concatenate([[0], np.cumsum(counts.numpy())]).astype(np.int64))
+
     def hist2_pack(self, keys, bounds, rec):
-        a, b, r = keys.numpy().view(np.uint32), bounds.numpy(), rec.numpy()
+        a, b, r = keys.numpy().view(np.uint32 if keys.element_size() == 4 else np.uint16), bounds.numpy(), rec.numpy()
         nb, over = b.size - 1, 0
         shifts = (2 * np.arange(16, dtype=np.uint32))
         for j in range(nb):
-            v = a[b[j]:b[j + 1]] & np.uint32(0xFFFF)
+            v = a[b[j]:b[j + 1]].astype(np.uint32) & np.uint32(0xFFFF)
             out = r[j * self.REC:(j + 1) * self.REC]
             out[:] = 0
             if v.size > 65535:

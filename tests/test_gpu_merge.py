@@ -328,6 +328,37 @@ def test_hist2_records_sum_to_the_sorted_bucket(ctx, nsrc, nb, per_bucket):
     assert (out[:n] == np.sort(allk)).all() and (out[n:] == 0xFFFFFFFF).all()
 
 
+def test_hist2_records_from_low_halves(ctx):
+    """msd_hist2_pack_u32_low16: the records packed from what msd_order_low16_u32 wrote equal those packed from the keys
+    ordered in place (the fields are a function of the bucket's multiset; the entries may come in another order)."""
+    import torch
+    from oracle import oracle as O
+    n = (1 << 22) + 5
+    k = O.gen_uniform_u32(n, seed=123) & np.uint32(0x00FFFFFF)        # 256 buckets of about 2^14 keys
+    k[:900] = np.uint32(0x00340000) | (np.arange(900, dtype=np.uint32) % np.uint32(50))   # 50 values with 18 copies each
+    RB = ctx.HIST2_RECORD_BYTES
+    t1 = dev(k)
+    ctx.sort_top(t1, 16)
+    b1 = ctx.bucket_bounds(t1, 16, 256)
+    r1 = torch.zeros(256 * RB, dtype=torch.uint8, device="cuda")
+    f1 = ctx.hist2_pack(t1, b1, r1)
+    t2 = dev(k)
+    low = torch.empty(n, dtype=torch.int16, device="cuda")
+    counts = ctx.order_low16(t2, low)
+    b2 = ctx.bounds_from_counts16(counts)
+    assert (b2[:257].cpu().numpy() == b1.cpu().numpy()).all() and int(b2[65536]) == n
+    r2 = torch.zeros(256 * RB, dtype=torch.uint8, device="cuda")
+    f2 = ctx.hist2_pack(low, b2[:257].contiguous(), r2)
+    assert int(f1.item()) == int(f2.item()) == 0
+    a1, a2 = r1.cpu().numpy().reshape(256, RB), r2.cpu().numpy().reshape(256, RB)
+    assert (a1[:, :16384] == a2[:, :16384]).all()
+    e1, e2 = a1[:, 16384:].copy().view(np.uint32), a2[:, 16384:].copy().view(np.uint32)
+    assert (e1[:, 0] == e2[:, 0]).all() and int(e1[:, 0].max()) > 100
+    for j in range(256):
+        c = int(e1[j, 0])
+        assert (np.sort(e1[j, 1:1 + c]) == np.sort(e2[j, 1:1 + c])).all()
+
+
 def test_hist2_many_copies_and_overflow(ctx):
     """Values with three and more copies travel as (value, copies) entries; a 256-value group with more keys in all than a
     16-bit offset addresses makes the receiver write the sources' histograms out one after the other (finished by the general

@@ -136,6 +136,10 @@ for it in range(3):
     flag = [None]
     note("fine, histograms: pack", timed(lambda: flag.__setitem__(0, ctx.hist2_pack(hk, bnd, rec_send))))
     assert int(flag[0].item()) == 0
+    cnt2 = ctx.order_low16(ok2, low2)      # (ok2 holds this iteration's shard ordered by its top 8 bits by now: any order does)
+    bnd2 = ctx.bounds_from_counts16(cnt2)
+    note("fine, histograms: pack from the low halves", timed(lambda: flag.__setitem__(0, ctx.hist2_pack(low2[:n], bnd2, rec_send))))
+    assert int(flag[0].item()) == 0
     for s_ in range(G):   # what rank 0 receives: per source the records of ITS buckets (here: of the arrived extents)
         part = a[s_ * chunk:(s_ + 1) * chunk]
         bp = ctx.bucket_bounds(part, 16, nbl)
@@ -175,6 +179,11 @@ print(json.dumps({"ranks": G, "keys_per_rank": n, "ms_best_of_3": ms,
                                        "post_ms": ms["fine, low halves: counting leaf over the arrived extents"],
                                        "local_ms_per_step": round(ms["fine, low halves: order + pack in one go"] + ms["fine, low halves: counting leaf over the arrived extents"], 3),
                                        "exchange_bytes_per_key": 2},
+                  "fine_hist_fused": {"pre_ms": round(ms["fine, low halves: order + pack in one go"] + ms["fine, histograms: pack from the low halves"], 3),
+                                      "post_ms": ms["fine, histograms: leaf summing the arrived records"],
+                                      "local_ms_per_step": round(ms["fine, low halves: order + pack in one go"] + ms["fine, histograms: pack from the low halves"]
+                                                                 + ms["fine, histograms: leaf summing the arrived records"], 3),
+                                      "exchange_bytes_per_key": round(65536 * 17408 / n, 3)},
                   "fine_hist": {"pre_ms": round(fine_pre + ms["fine, histograms: pack"], 3),
                                 "post_ms": ms["fine, histograms: leaf summing the arrived records"],
                                 "local_ms_per_step": round(fine_pre + ms["fine, histograms: pack"] + ms["fine, histograms: leaf summing the arrived records"], 3),
