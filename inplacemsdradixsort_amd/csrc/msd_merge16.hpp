@@ -857,14 +857,42 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 	uint32_t *bad = exc + (kH2MaxExc + 1);             // a byte counter has overflowed
 	const uint32_t tid0 = threadIdx.x;
 	auto rfl = [](uint32_t x) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(x); };
+	constexpr int U = sizeof(IN) == 2 ? 4 : 8; // 16-byte vectors in flight per thread: all of a 2^14-key bucket at once
+	// a bucket on the array's 16-byte grid: single elements at both ends, whole vectors [vfirst, vend) between them
+	struct Where {
+		const IN *base;
+		uint32_t n, o, tot, vfirst, vend;
+		bool fits;
+	};
+	auto where = [&](uint32_t bb) -> Where {
+		const uint64_t s0 = bounds[bb], s1 = bounds[bb + 1];
+		const uint64_t s = (uint64_t)rfl((uint32_t)s0) | ((uint64_t)rfl((uint32_t)(s0 >> 32)) << 32);
+		const uint64_t e = (uint64_t)rfl((uint32_t)s1) | ((uint64_t)rfl((uint32_t)(s1 >> 32)) << 32);
+		Where wq;
+		wq.fits = e - s <= 65535u;
+		wq.n = wq.fits ? (uint32_t)(e - s) : 0u;
+		wq.o = (uint32_t)(s & (VE - 1u));
+		wq.tot = wq.n + wq.o;
+		wq.vend = wq.tot / VE;
+		wq.vfirst = wq.o ? 1u : 0u;
+		wq.base = keys + (s - wq.o);
+		return wq;
+	};
+	// (branch-free loads: lanes behind the end read the bucket's last vector -- or, for an empty bucket, the array's first -- again)
+	auto load_batch = [&](const Where &wq, uint32_t v0, uint32_t tq, u32x4 (&q)[U]) {
+		const u32x4 *bp = wq.vend > 0 ? reinterpret_cast<const u32x4 *>(wq.base) : reinterpret_cast<const u32x4 *>(keys);
+		const uint32_t last = wq.vend > 0 ? wq.vend - 1u : 0u;
+#pragma unroll
+		for (int u = 0; u < U; ++u) q[u] = __builtin_nontemporal_load(bp + min(v0 + (uint32_t)u * TH + tq, last));
+	};
+	u32x4 q[U]; // the first batch of the bucket at hand: requested while the bucket before it is packed
+	if (blockIdx.x < nb) load_batch(where(blockIdx.x), where(blockIdx.x).vfirst, tid0, q);
 	for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
 		uint32_t tid = tid0;
 		asm volatile("" : "+v"(tid));
-		const uint64_t s0 = bounds[b], s1 = bounds[b + 1];
-		const uint64_t s = (uint64_t)rfl((uint32_t)s0) | ((uint64_t)rfl((uint32_t)(s0 >> 32)) << 32);
-		const uint64_t e = (uint64_t)rfl((uint32_t)s1) | ((uint64_t)rfl((uint32_t)(s1 >> 32)) << 32);
-		const bool fits = e - s <= 65535u;
-		const uint32_t n = fits ? (uint32_t)(e - s) : 0u;
+		const Where wb = where(b);
+		const bool fits = wb.fits;
+		const uint32_t n = wb.n;
 		for (uint32_t j = tid; j < kH2Words / 4; j += TH) reinterpret_cast<u32x4 *>(cw)[j] = u32x4{ 0u, 0u, 0u, 0u };
 		if (tid < (kH2MaxExc + 1) / 4) reinterpret_cast<u32x4 *>(exc)[tid] = u32x4{ 0u, 0u, 0u, 0u };
 		if (tid == 0) {
@@ -877,47 +905,46 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 			const uint32_t v = key & 0xFFFFu;
 			(void)__hip_atomic_fetch_add(&cw[h2_at(v >> 2)], 1u << ((v & 3u) << 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		};
-		{ // the bucket on the array's 16-byte grid: single elements at both ends, whole vectors between them
-			const uint32_t o = (uint32_t)(s & (VE - 1u)), tot = n + o, vend = tot / VE, vfirst = o ? 1u : 0u;
-			const IN *base = keys + (s - o);
-			if (n && tid < VE) {
-				if (o && tid >= o && tid < tot) count(base[tid]);
-				const uint32_t el = vend * VE + tid;
-				if (el < tot && (vend > 0 || o == 0)) count(base[el]);
-			}
-			// (eight vectors in flight per thread -- all of a 2^14-key bucket at once; branch-free loads: lanes behind the end
-			// read the last vector again and ignore it)
-			constexpr int U = sizeof(IN) == 2 ? 4 : 8;
-			for (uint32_t v0 = vfirst; v0 < vend; v0 += U * TH) {
-				u32x4 q[U];
+		auto eat = [&](const u32x4 (&qq)[U], uint32_t v0) {
 #pragma unroll
-				for (int u = 0; u < U; ++u)
-					q[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base) + min(v0 + (uint32_t)u * TH + tid, vend - 1u));
-#pragma unroll
-				for (int u = 0; u < U; ++u) {
-					if (v0 + (uint32_t)u * TH + tid < vend) {
-						count(q[u].x);
-						count(q[u].y);
-						count(q[u].z);
-						count(q[u].w);
-						if constexpr (sizeof(IN) == 2) { // (eight low halves per vector; count() masks the value)
-							count(q[u].x >> 16);
-							count(q[u].y >> 16);
-							count(q[u].z >> 16);
-							count(q[u].w >> 16);
-						}
+			for (int u = 0; u < U; ++u) {
+				if (v0 + (uint32_t)u * TH + tid < wb.vend) {
+					count(qq[u].x);
+					count(qq[u].y);
+					count(qq[u].z);
+					count(qq[u].w);
+					if constexpr (sizeof(IN) == 2) { // (eight low halves per vector; count() masks the value)
+						count(qq[u].x >> 16);
+						count(qq[u].y >> 16);
+						count(qq[u].z >> 16);
+						count(qq[u].w >> 16);
 					}
 				}
 			}
+		};
+		if (n && tid < VE) {
+			if (wb.o && tid >= wb.o && tid < wb.tot) count(wb.base[tid]);
+			const uint32_t el = wb.vend * VE + tid;
+			if (el < wb.tot && (wb.vend > 0 || wb.o == 0)) count(wb.base[el]);
+		}
+		eat(q, wb.vfirst);
+		for (uint32_t v0 = wb.vfirst + U * TH; v0 < wb.vend; v0 += U * TH) { // (buckets of more than 2^14 keys)
+			u32x4 q2[U];
+			load_batch(wb, v0, tid, q2);
+			eat(q2, v0);
+		}
+		{ // the next bucket's first batch is on its way while this one is packed (past the last bucket: the last one again, unused)
+			const Where wn = where(min(b + gridDim.x, nb - 1u));
+			load_batch(wn, wn.vfirst, tid, q);
 		}
 		__syncthreads();
 		// ---- thread t packs values [128 t, 128 t + 128) = 32 counter words into 32 bytes of fields
 		const u32x4 *cq = reinterpret_cast<const u32x4 *>(cw + h2_at(tid * 32u));
-		uint32_t out[8], bsum = 0;
+		uint32_t out[8], bsum = 0, many = 0; // many: bit = a word of mine that holds a value with three or more copies
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
-			const u32x4 q = cq[j];
-			const uint32_t wq[4] = { q.x, q.y, q.z, q.w };
+			const u32x4 qc = cq[j];
+			const uint32_t wq[4] = { qc.x, qc.y, qc.z, qc.w };
 			uint32_t o4 = 0;
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
@@ -927,17 +954,23 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 				const uint32_t nz = ((((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi) & 0x80808080u) >> 7;
 				const uint32_t f = (w & 0x03030303u) | (nz * 3u);
 				o4 |= ((f | (f >> 6) | (f >> 12) | (f >> 18)) & 0xFFu) << (8 * i);
-				if ((f & (f >> 1) & 0x01010101u) != 0u) { // (rare) a value with three or more copies
-					for (uint32_t k2 = 0; k2 < 4; ++k2) {
-						const uint32_t c = (w >> (8 * k2)) & 0xFFu;
-						if (c >= 3u) {
-							const uint32_t k = atomicAdd(&exc[0], 1u);
-							if (k < kH2MaxExc) exc[1u + k] = ((tid * 128u + 16u * j + 4u * i + k2) << 16) | c;
-						}
-					}
-				}
+				many |= (f & (f >> 1) & 0x01010101u) != 0u ? 1u << (4 * j + i) : 0u;
 			}
 			out[j] = o4;
+		}
+		// (one value in five hundred has three or more copies: listed behind the loop -- inside it, some lane of nearly every
+		// wave took the branch at nearly every word)
+		while (many) {
+			const uint32_t wi = (uint32_t)__builtin_ctz(many);
+			many &= many - 1u;
+			const uint32_t w = cw[h2_at(tid * 32u + wi)];
+			for (uint32_t k2 = 0; k2 < 4; ++k2) {
+				const uint32_t c = (w >> (8 * k2)) & 0xFFu;
+				if (c >= 3u) {
+					const uint32_t k = atomicAdd(&exc[0], 1u);
+					if (k < kH2MaxExc) exc[1u + k] = ((tid * 128u + 4u * wi + k2) << 16) | c;
+				}
+			}
 		}
 		{ // the bytes must add up to the bucket's keys: a counter that passed 255 has carried into its neighbour (or out of its word)
 			uint32_t t = (bsum & 0xFFFFu) + (bsum >> 16);
