@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 	uint32_t *gbase = cw + kMcCwWords;                 // 257 group bases
 	uint32_t *stage = gbase + 272;                     // 256 output positions per wave
 	uint32_t *wtot = stage + (kMcTh / 64) * kMcSeg;    // 16 wave totals
-	uint32_t *flags = wtot + 16;                       // [0] next ticket, [1] crowded
+	uint32_t *flags = wtot + 16;                       // [0] next ticket, [1] crowded, [2] next output segment
 	uint32_t *ext = flags + 4;                         // the bucket's extents: start (2 words), length; up to 16
 	uint16_t *seg_va = reinterpret_cast<uint16_t *>(ext + 48); // the value whose run holds every segment's first key (+ one behind the last)
 	const uint32_t tid0 = threadIdx.x;
@@ -497,6 +497,7 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 		if (tid == 0) {
 			flags[0] = atomicAdd(ticket, 1u) + gridDim.x;
 			flags[1] = 0;
+			flags[2] = TH / 64; // the next output segment a wave may take (the first TH / 64 are the waves' own)
 		}
 		MSD_STAMP(0); // clear + ticket
 		__syncthreads();
@@ -696,7 +697,8 @@ __global__ __launch_bounds__(kMcTh) void merge_count_kernel(const IN *src, uint3
 			// stores its four keys as one 16-byte vector on the output's grid
 			uint32_t *segb = dst + (d - off);
 			uint32_t *wst = stage + (w << 8);
-			for (uint32_t sgi = w; sgi < nseg; sgi += TH / 64) {
+			// (segments by ticket, not round robin: the waves of a workgroup finished 20 thousand cycles apart)
+			for (uint32_t sgi = w; sgi < nseg; sgi = rfl(lane == 0 ? atomicAdd(&flags[2], 1u) : 0u)) {
 				const uint32_t va = rfl(seg_va[sgi]), vb = min(rfl(seg_va[sgi + 1]), mask); // (no key has a value above the mask)
 				const uint32_t q0 = sgi * kMcSeg;
 				const uint32_t plo = (q0 > off ? q0 : off) - off, phi = min(q0 + kMcSeg, n + off) - off; // the segment in bucket positions
