@@ -176,6 +176,11 @@ int msd_pack_low16_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint16_
  * on, in any order inside the bucket), into d_out (n uint16, no overlap with d_keys).  d_keys is left ordered by its top 8
  * bits.  Blocks the calling thread for the in-place round; the rest is asynchronous. */
 int msd_order_low16_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint16_t *d_out, uint64_t *d_counts);
+/* ... in two halves: d_counts is complete (in stream order) after the first, so that the caller can start exchanging the
+ * counts with the other ranks while the second -- the scatter, 2 ms per 2^30 keys -- runs.  The scatter must be the
+ * context's next call after the counts, on the same keys (MSD_EINVAL otherwise). */
+int msd_order_low16_counts_u32(msd_ctx *ctx, uint32_t *d_keys, uint64_t n, uint64_t *d_counts);
+int msd_order_low16_scatter_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, uint16_t *d_out);
 uint64_t msd_hist2_record_bytes(void);
 int msd_hist2_pack_u32(msd_ctx *ctx, const uint32_t *d_keys, uint64_t n, const uint64_t *d_bounds, uint32_t nbuckets, void *d_rec,
 		       uint64_t rec_bytes, uint32_t *d_overflow);

@@ -21,7 +21,7 @@ EXPORTS = [
     "msd_partition_u32", "msd_partition_u64", "msd_partition_pairs_u64",
     "msd_sample_u32", "msd_splitters_u32", "msd_partition_by_splitters_u32",
     "msd_sample_u64", "msd_splitters_u64", "msd_partition_by_splitters_u64", "msd_partition_by_splitters_pairs_u64",
-    "msd_sort_u32_top", "msd_sort_u64_top", "msd_sort_pairs_u64_top", "msd_bucket_bounds_u32", "msd_bucket_bounds_u64", "msd_merge_buckets_u32", "msd_pack_low16_u32", "msd_order_low16_u32", "msd_merge_buckets_u32_low16", "msd_hist2_record_bytes", "msd_hist2_pack_u32", "msd_hist2_pack_u32_low16", "msd_bounds_from_counts16", "msd_merge_buckets_u32_hist2",
+    "msd_sort_u32_top", "msd_sort_u64_top", "msd_sort_pairs_u64_top", "msd_bucket_bounds_u32", "msd_bucket_bounds_u64", "msd_merge_buckets_u32", "msd_pack_low16_u32", "msd_order_low16_u32", "msd_order_low16_counts_u32", "msd_order_low16_scatter_u32", "msd_merge_buckets_u32_low16", "msd_hist2_record_bytes", "msd_hist2_pack_u32", "msd_hist2_pack_u32_low16", "msd_bounds_from_counts16", "msd_merge_buckets_u32_hist2",
     "msd_sort_u32_segments", "msd_sort_u64_segments", "msd_sort_pairs_u64_segments", "msd_gather_runs_u32", "msd_gather_runs_u64",
     "msd_check_u32", "msd_check_u64",
     "msd_gen_uniform_u32", "msd_gen_uniform_u64", "msd_gen_zipf_u32", "msd_gen_iota_u64",
@@ -108,6 +108,8 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     L.msd_merge_buckets_u32_low16.argtypes = [_vp, _vp, _u64, _vp, _u64p, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _u64, _u64]
     L.msd_pack_low16_u32.argtypes = [_vp, _vp, _u64, _vp]
     L.msd_order_low16_u32.argtypes = [_vp, _vp, _u64, _vp, _vp]
+    L.msd_order_low16_counts_u32.argtypes = [_vp, _vp, _u64, _vp]
+    L.msd_order_low16_scatter_u32.argtypes = [_vp, _vp, _u64, _vp]
     L.msd_hist2_record_bytes.restype = C.c_uint64
     L.msd_hist2_record_bytes.argtypes = []
     L.msd_hist2_pack_u32.argtypes = [_vp, _vp, _u64, _vp, C.c_uint32, _vp, _u64, _vp]

@@ -163,6 +163,19 @@ class MsdContext:
         self._ok(self._L.msd_order_low16_u32(self._h, self._ptr(keys, 4), keys.numel(), self._ptr(out, 2), C.c_void_p(counts.data_ptr())))
         return counts
 
+    def order_low16_counts(self, keys):
+        """First half of :meth:`order_low16`: the 2^16 bucket sizes (ready in stream order); :meth:`order_low16_scatter` must
+        be this context's next call."""
+        torch = _torch()
+        counts = torch.empty(65536, dtype=torch.int64, device=keys.device)
+        self._ok(self._L.msd_order_low16_counts_u32(self._h, self._ptr(keys, 4), keys.numel(), C.c_void_p(counts.data_ptr())))
+        return counts
+
+    def order_low16_scatter(self, keys, out) -> None:
+        if out.element_size() != 2 or out.numel() < keys.numel():
+            raise MsdError("order_low16: an int16 buffer at least as long as the keys")
+        self._ok(self._L.msd_order_low16_scatter_u32(self._h, self._ptr(keys, 4), keys.numel(), self._ptr(out, 2)))
+
     def pack_low16(self, keys, out) -> None:
         """``out`` (int16, >= keys.numel() elements) <- the low 16 bits of the u32 ``keys``, in order."""
         if keys.element_size() != 4 or out.element_size() != 2 or out.numel() < keys.numel():

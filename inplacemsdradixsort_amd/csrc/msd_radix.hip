@@ -58,6 +58,8 @@ struct msd_ctx {
 	int leaf17 = 1;        // u64 keys and tuples: segments of <= 17408 elements are finished by leaf17_kernel (0: tuples: register partition + small leaves, keys: leaf_count_sort_kernel; A/B comparisons)
 	int stream_kernel = 2; // streaming classify: 2 = classify_stream2_kernel (lean tile loop), 1 = classify_kernel (round 2; A/B comparisons)
 	int mid_leaf = 1;      // u32 keys: merge_count_kernel (list mode) in front of count_walk_kernel (0: A/B comparisons)
+	const uint32_t *order_keys = nullptr; // msd_order_low16_counts_u32 has run on these keys and its tables are still in the slab
+	uint64_t order_n = 0;
 	int merge_leaf = 0;    // msd_merge_buckets_u32: 0 = by bucket size, 1 = merge_place16_kernel, 2 = merge_count_kernel (tests)
 };
 
@@ -120,7 +122,11 @@ static int dev_reserve(msd_ctx *c, char *&p, size_t &have, size_t bytes, bool ex
 	have = bytes;
 	return MSD_OK;
 }
-static int slab_reserve(msd_ctx *c, size_t bytes, bool exact = false) { return dev_reserve(c, c->slab, c->slab_bytes, bytes, exact); }
+static int slab_reserve(msd_ctx *c, size_t bytes, bool exact = false)
+{
+	c->order_keys = nullptr; // (whoever reserves the slab overwrites the tables a pending msd_order_low16_scatter_u32 would read)
+	return dev_reserve(c, c->slab, c->slab_bytes, bytes, exact);
+}
 static int keep_reserve(msd_ctx *c, size_t bytes, bool exact = false) { return dev_reserve(c, c->keep, c->keep_bytes, bytes, exact); }
 
 // Leaf lists grow between rounds (the host knows how many children a round can add);
@@ -1703,20 +1709,19 @@ int msd_bounds_from_counts16(msd_ctx *c, const uint64_t *d_counts, uint64_t *d_b
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
 }
-int msd_order_low16_u32(msd_ctx *c, uint32_t *d_keys, uint64_t n, uint16_t *d_out, uint64_t *d_counts)
+// msd_order_low16_u32 in two halves: the counts are ready (asynchronously) after the first, so that the caller can start its
+// count exchange with the other ranks while the second -- the scatter, 2 ms per 2^30 keys -- runs
+int msd_order_low16_counts_u32(msd_ctx *c, uint32_t *d_keys, uint64_t n, uint64_t *d_counts)
 {
 	if (!c) return MSD_EINVAL;
-	if (!d_out || !d_counts || (n && !d_keys)) return fail(c, MSD_EINVAL, "order_low16: null pointer");
-	if (((uintptr_t)d_keys & 15) || ((uintptr_t)d_out & 15)) return fail(c, MSD_EINVAL, "order_low16: buffers must be 16-byte aligned");
+	c->order_keys = nullptr;
+	if (!d_counts || (n && !d_keys)) return fail(c, MSD_EINVAL, "order_low16: null pointer");
+	if ((uintptr_t)d_keys & 15) return fail(c, MSD_EINVAL, "order_low16: buffers must be 16-byte aligned");
 	if (n >= (1ull << 40)) return fail(c, MSD_EINVAL, "order_low16: too many keys");
-	{
-		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * 4, d0 = (uintptr_t)d_out, d1 = d0 + n * 2;
-		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "order_low16: source and destination overlap");
-	}
 	// one in-place round on the top 8 bits (the direct-placement round 0) ...
 	int rc = sort_impl<uint32_t, NoVal>(c, d_keys, nullptr, n, 32, false, 0, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 24u);
 	if (rc) return rc;
-	// ... exact counts of all upper halves, bucket starts, and the low halves scattered to their buckets' places in d_out
+	// ... exact counts of all upper halves and the place of every workgroup's share of every bucket
 	HIPCHK(c, hipSetDevice(c->device));
 	Bump sz(nullptr), *bp = &sz;
 	uint64_t *pb = nullptr;
@@ -1736,10 +1741,39 @@ int msd_order_low16_u32(msd_ctx *c, uint32_t *d_keys, uint64_t n, uint16_t *d_ou
 	hipLaunchKernelGGL((bucket_bounds_kernel<uint32_t>), dim3(2), dim3(256), 0, c->stream, (const uint32_t *)d_keys, n, 24u, (uint64_t)0, 256u, pb);
 	hipLaunchKernelGGL(hist16_kernel, dim3(256 * kS16Chunks), dim3(kS16Th), 0, c->stream, (const uint32_t *)d_keys, n, (const uint64_t *)pb, wg);
 	hipLaunchKernelGGL(scan16_kernel, dim3(256), dim3(256), 0, c->stream, (const uint32_t *)wg, (const uint64_t *)pb, (unsigned long long *)d_counts, base);
-	hipLaunchKernelGGL(scatter_low16_kernel, dim3(256 * kS16Chunks), dim3(kS16Th), kS16Lds, c->stream, (const uint32_t *)d_keys, n, (const uint64_t *)pb,
-			   (const unsigned long long *)base, d_out);
+	HIPCHK(c, hipGetLastError());
+	c->order_keys = d_keys; // (the tables of the scatter lie in the slab: the scatter must be this context's next call)
+	c->order_n = n;
+	return MSD_OK;
+}
+int msd_order_low16_scatter_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, uint16_t *d_out)
+{
+	if (!c) return MSD_EINVAL;
+	if (!d_out || (n && !d_keys)) return fail(c, MSD_EINVAL, "order_low16: null pointer");
+	if (c->order_keys != d_keys || c->order_n != n) return fail(c, MSD_EINVAL, "order_low16_scatter: not preceded by msd_order_low16_counts_u32 on the same keys");
+	c->order_keys = nullptr;
+	if ((uintptr_t)d_out & 15) return fail(c, MSD_EINVAL, "order_low16: buffers must be 16-byte aligned");
+	{
+		const uintptr_t s0 = (uintptr_t)d_keys, s1 = s0 + n * 4, d0 = (uintptr_t)d_out, d1 = d0 + n * 2;
+		if (s0 < d1 && d0 < s1) return fail(c, MSD_EINVAL, "order_low16: source and destination overlap");
+	}
+	HIPCHK(c, hipSetDevice(c->device));
+	Bump real(c->slab); // (as carved by msd_order_low16_counts_u32)
+	const uint64_t *pb = real.take<uint64_t>(257);
+	(void)real.take<uint32_t>((size_t)65536 * kS16Chunks);
+	const unsigned long long *base = real.take<unsigned long long>((size_t)65536 * kS16Chunks);
+	if (n)
+		hipLaunchKernelGGL(scatter_low16_kernel, dim3(256 * kS16Chunks), dim3(kS16Th), kS16Lds, c->stream, d_keys, n, pb, base, d_out);
 	HIPCHK(c, hipGetLastError());
 	return MSD_OK;
+}
+int msd_order_low16_u32(msd_ctx *c, uint32_t *d_keys, uint64_t n, uint16_t *d_out, uint64_t *d_counts)
+{
+	if (!c) return MSD_EINVAL;
+	if (!d_out) return fail(c, MSD_EINVAL, "order_low16: null pointer");
+	int rc = msd_order_low16_counts_u32(c, d_keys, n, d_counts);
+	if (!rc) rc = msd_order_low16_scatter_u32(c, d_keys, n, d_out);
+	return rc;
 }
 int msd_pack_low16_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, uint16_t *d_out)
 {

@@ -222,7 +222,15 @@ def use_fine(n_keys: int, world: int, have_work: bool, scheme=None, _force_excha
     return world <= 8 and n_keys >= FINE_MIN_KEYS
 
 
-def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None, hist_ok=None):
+def _takes_async(fn) -> bool:
+    import inspect
+    try:
+        return "async_op" in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None, hist_ok=None, between=None):
     """The fine scheme's count exchange: ``counts`` = this rank's 2^16 bucket sizes (int64, on the device).  One
     all-gather of 2^16 + 1 int64 per rank; the world x world send matrix and the capacities come to the host in ONE
     small copy, the per-bucket counts stay on the device.  Returns (send_list, recv_list, mine): ``mine`` = int64
@@ -235,7 +243,16 @@ def exchange_fine_counts(dist, counts, capacity: int, world: int, group=None, hi
     flag = (hist_ok.to(torch.int64).reshape(1) != 0).to(torch.int64) if hist_ok is not None else torch.zeros(1, dtype=torch.int64, device=counts.device)
     row = torch.cat([counts.to(torch.int64), torch.tensor([capacity], dtype=torch.int64, device=counts.device), flag])
     rows = [torch.empty_like(row) for _ in range(world)]
-    dist.all_gather(rows, row, group=group)
+    # (between: device work that does not depend on the other ranks' counts -- the scatter of the low halves -- is queued while
+    # the counts travel and the host waits for them; with a backend whose collectives block the host it is queued first)
+    if between is not None and _takes_async(dist.all_gather):
+        h = dist.all_gather(rows, row, group=group, async_op=True)
+        between()
+        h.wait()
+    else:
+        if between is not None:
+            between()
+        dist.all_gather(rows, row, group=group)
     allc = torch.stack(rows)                                      # [sender, bucket | capacity | records ready], on the device
     nbl = nb // world
     to_rank = allc[:, :nb].view(world, world, nbl).sum(dim=2)     # [sender, destination]
@@ -302,7 +319,8 @@ def _as_low16(buf):
 
 def _fine_counts(engine, keys, rec=None, world: int = 1, send16=None):
     """What a rank does before the fine exchange.  Returns (its 2^16 bucket sizes -- int64, on the device --, the flag "my
-    buckets are ready in ``rec`` as histogram records" or None, "the low halves are ready in ``send16``").
+    buckets are ready in ``rec`` as histogram records" or None, "the low halves are ready in ``send16``": True, False, or a
+    callable that makes them ready and is to be called once -- while the counts are exchanged).
     * histogram records wanted (``rec`` holds 2^16 of them, few ranks, a big shard): ``engine.order_low16`` as below, then
       the records are packed from the low halves (``engine.hist2_pack``); without ``send16`` the shard is ordered in place by
       its top 16 bits (``engine.sort_top``) and the records are packed from the keys;
@@ -313,6 +331,8 @@ def _fine_counts(engine, keys, rec=None, world: int = 1, send16=None):
     want_hist = (rec is not None and FINE_HIST and world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS
                  and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES)
     if not want_hist and FINE_LOW16 and send16 is not None and send16.numel() >= keys.numel() and hasattr(engine, "order_low16"):
+        if hasattr(engine, "order_low16_counts"):   # the scatter runs while the counts are exchanged (exchange_fine_counts' `between`)
+            return engine.order_low16_counts(keys), None, (lambda: engine.order_low16_scatter(keys, send16))
         return engine.order_low16(keys, send16), None, True
     if want_hist and FINE_LOW16 and send16 is not None and send16.numel() >= keys.numel() and hasattr(engine, "order_low16"):
         # (the records are packed from the low halves order_low16 has written -- which are then also ready for the case that
@@ -386,7 +406,9 @@ def sort_sharded_u32(engine, keys, recv, dist, world: int, group=None, work=None
             if FINE_HIST and world <= FINE_HIST_MAX_WORLD and keys.numel() >= FINE_HIST_MIN_KEYS and rec.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES:
                 s16 = None
         counts, hist_ok, packed = _fine_counts(engine, keys, rec, world, s16)
-        send_l, got_l, mine = exchange_fine_counts(dist, counts, min(recv.numel(), work.numel()), world, group, hist_ok)
+        finish = packed if callable(packed) else None
+        send_l, got_l, mine = exchange_fine_counts(dist, counts, min(recv.numel(), work.numel()), world, group, hist_ok, finish)
+        packed = True if finish is not None else packed
         m = int(sum(got_l))
         if send_l.use_hist and 4 * recv.numel() >= (1 << FINE_BITS) * HIST2_RECORD_BYTES:
             sp = _hist_splits(world)
@@ -542,7 +564,9 @@ class ShardedSorter:
                     self._send16[slot] = torch.empty(keys.numel(), dtype=torch.int16, device=keys.device)
                 send16 = self._send16[slot][:keys.numel()]
             counts, hist_ok, packed = _fine_counts(self.engine, keys, rec, self.world, send16)
-            send_l, got_l, mine = exchange_fine_counts(self.dist, counts, cap, self.world, self.group, hist_ok)  # raises on all ranks
+            finish = packed if callable(packed) else None
+            send_l, got_l, mine = exchange_fine_counts(self.dist, counts, cap, self.world, self.group, hist_ok, finish)  # raises on all ranks
+            packed = True if finish is not None else packed
             self._slot = (self._slot + 1) % len(self.recv)
             self.last_format = "histogram records" if send_l.use_hist else "low halves" if FINE_LOW16 else "whole keys"
             if send_l.use_hist:

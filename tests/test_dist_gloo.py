@@ -101,6 +101,13 @@ class NumpyEngine:
         a[:] = a[np.argsort(a >> np.uint32(24), kind="stable")]       # (the shard is left ordered by its top 8 bits)
         return torch.from_numpy(counts)
 
+    def order_low16_counts(self, keys):
+        a = keys.numpy().view(np.uint32)
+        return torch.from_numpy(np.bincount(a >> np.uint32(16), minlength=65536).astype(np.int64))
+
+    def order_low16_scatter(self, keys, out):
+        self.order_low16(keys, out)
+
     def pack_low16(self, keys, out):
         out.numpy().view(np.uint16)[:keys.numel()] = keys.numpy().view(np.uint32).astype(np.uint16)
 
