@@ -7,9 +7,11 @@ sort on 2^30 uniform u32 keys per GPU (BASELINE.json configs[1]; configs[3] for 
 
 A "step" sorts one fresh array of 2^LOGN uniform keys that is already resident in
 HBM (arrays for all W+K steps are generated before the timed region).  For N>1
-every rank holds its own 2^LOGN shard (weak scaling): one in-place top-digit pass
-packs the send side, one RCCL all-to-all exchanges key ranges, each rank sorts
-what it received; value = all ranks' keys / max-over-ranks time.
+every rank holds its own 2^LOGN shard (weak scaling): the shard is ordered by its
+upper halves, one RCCL all-to-all exchanges key ranges -- as the keys' low halves,
+at 2 ranks as histogram records of the buckets --, one counting
+pass finishes what arrived; exchange s runs under the local work of steps s - 1 and
+s + 1; value = all ranks' keys / max-over-ranks time.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      -- dominant kernel: algorithmic bytes / HIP-event time vs 8 TB/s (N > 1: the whole local sort per GPU,
