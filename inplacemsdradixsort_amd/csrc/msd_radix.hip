@@ -1730,7 +1730,7 @@ int msd_order_low16_counts_u32(msd_ctx *c, uint32_t *d_keys, uint64_t n, uint64_
 	auto carve = [&]() {
 		pb = bp->take<uint64_t>(257);
 		wg = bp->take<uint32_t>((size_t)65536 * kS16Chunks);
-		base = bp->take<unsigned long long>((size_t)65536 * kS16Chunks);
+		base = bp->take<unsigned long long>((size_t)65536 * kS16Chunks + 1);
 	};
 	carve();
 	rc = slab_reserve(c, sz.off + 4096);
@@ -1761,7 +1761,7 @@ int msd_order_low16_scatter_u32(msd_ctx *c, const uint32_t *d_keys, uint64_t n, 
 	Bump real(c->slab); // (as carved by msd_order_low16_counts_u32)
 	const uint64_t *pb = real.take<uint64_t>(257);
 	(void)real.take<uint32_t>((size_t)65536 * kS16Chunks);
-	const unsigned long long *base = real.take<unsigned long long>((size_t)65536 * kS16Chunks);
+	const unsigned long long *base = real.take<unsigned long long>((size_t)65536 * kS16Chunks + 1);
 	if (n)
 		hipLaunchKernelGGL(scatter_low16_kernel, dim3(256 * kS16Chunks), dim3(kS16Th), kS16Lds, c->stream, d_keys, n, pb, base, d_out);
 	HIPCHK(c, hipGetLastError());

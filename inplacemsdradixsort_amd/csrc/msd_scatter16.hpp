@@ -32,7 +32,7 @@ constexpr uint32_t kS16Chunks = MSD_S16_CHUNKS; // workgroups per top-byte paren
 constexpr int kS16Vec = MSD_S16_VEC;            // 16-byte vectors per thread and tile
 constexpr int kS16Kpt = 4 * kS16Vec;            // keys per thread and tile
 constexpr uint32_t kS16Tile = kS16Th * kS16Kpt;
-constexpr size_t kS16Lds = (size_t)256 * kS16Cap * 2 + 256 * 8 + 256 * 4; // rings | places | fill
+constexpr size_t kS16Lds = (size_t)256 * kS16Cap * 2 + 256 * 8 + 256 * 8 + 256 * 4 + 256 * 4; // rings | places | ends | fill | skip
 static_assert(2 * kS16Lds <= 160 * 1024, "two workgroups per CU");
 
 // chunk j of parent p (the keys whose top byte is p lie in [pb[p], pb[p + 1])): whole 16-byte vectors of the parent's range
@@ -119,8 +119,14 @@ __global__ __launch_bounds__(256) void scan16_kernel(const uint32_t *__restrict_
 		base[((size_t)p * 256u + c) * kS16Chunks + j] = at;
 		at += part[j];
 	}
+	if (p == 255u && c == 255u) base[(size_t)65536 * kS16Chunks] = at; // (one behind the last: a share ends where the next begins)
 }
 
+// Write alignment.  A workgroup's share of a bucket starts wherever the shares before it end -- at any 2-byte address --, and
+// 128-byte blocks written from there straddle three 64-byte granules instead of two (PMC: 2.99 GB written per 2^30 keys
+// where 2.15 are stored; 2.18 GB since -- profiles/r03_pmc_order_low16.txt).  So a ring starts its life as if it already held k values, k = the share's distance from the
+// 128-byte boundary below it: every half-ring then leaves for a 128-byte-aligned place, as whole dwords; only the first one
+// of a share skips its k phantom values (2-byte stores, once per share), and the last, partial one is written in pieces.
 __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t *__restrict__ keys, uint64_t n, const uint64_t *__restrict__ pb,
 	const unsigned long long *__restrict__ base, uint16_t *__restrict__ out)
 {
@@ -129,16 +135,23 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 	static_assert(CAP == 128 && kS16Th == 512, "a bucket's buffer is two halves of 64 values; a wave looks after 32 buckets");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint16_t *buf = reinterpret_cast<uint16_t *>(smem);                                        // 256 rings of CAP values
-	unsigned long long *dstp = reinterpret_cast<unsigned long long *>(smem + (size_t)256 * CAP * 2); // where a bucket's next values go
-	uint32_t *cnt = reinterpret_cast<uint32_t *>(dstp + 256);                                  // per bucket: values in the ring | first half-ring << 16
+	unsigned long long *dstp = reinterpret_cast<unsigned long long *>(smem + (size_t)256 * CAP * 2); // the place of the ring's first half (aligned; before the share's start at first)
+	unsigned long long *tail = dstp + 256;                                                     // the share's end: keys that find the ring full go there, backwards
+	uint32_t *cnt = reinterpret_cast<uint32_t *>(tail + 256);                                  // per bucket: values in the ring (phantoms included) | first half-ring << 16
+	uint32_t *skip = cnt + 256;                                                                // phantom values at the start of the ring's first half
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
 	const uint32_t p = blockIdx.x / kS16Chunks, j = blockIdx.x % kS16Chunks;
 	uint64_t a, b;
 	s16_chunk(pb, p, j, a, b);
 	if (a >= b) return;
 	if (tid < 256) {
-		cnt[tid] = 0;
-		dstp[tid] = base[((size_t)p * 256u + tid) * kS16Chunks + j];
+		const size_t at = ((size_t)p * 256u + tid) * kS16Chunks + j;
+		const unsigned long long b0 = base[at];
+		const uint32_t ph = (uint32_t)((reinterpret_cast<uintptr_t>(out + b0) >> 1) & 63u);
+		cnt[tid] = ph;
+		skip[tid] = ph;
+		dstp[tid] = b0 - ph; // (may lie before the array: nothing is written below b0)
+		tail[tid] = base[at + 1];
 	}
 	__syncthreads();
 	const uint64_t va = a & ~3ull; // the chunk on the array's 16-byte grid
@@ -147,6 +160,10 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 	// a wave looks after buckets 32 w .. 32 w + 31: lane l after the first (l < 32) or second (l >= 32) unwritten half-ring
 	// of bucket 32 w + (l & 31)
 	const uint32_t myc = 32u * w + (lane & 31u), myhalf = lane >> 5;
+	auto lane64 = [&](unsigned long long x, int l) -> unsigned long long {
+		return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l) |
+		       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l) << 32);
+	};
 	for (uint64_t t0 = va; t0 < b; t0 += kS16Tile) {
 		uint32_t got[kS16Kpt];
 #pragma unroll
@@ -157,9 +174,9 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 				const uint32_t c = (k[u] >> 16) & 255u, in_ring = got[u] & 0xFFFFu, first = got[u] >> 16;
 				if (in_ring < CAP)
 					buf[c * CAP + ((64u * first + in_ring) & (CAP - 1u))] = (uint16_t)k[u];
-				else { // (its ring is full -- a bucket that takes more than 64 of a tile's keys, tile after tile: one by one, to a
-					// place of this chunk's own claimed in LDS)
-					const unsigned long long g = atomicAdd(&dstp[c], 1ull);
+				else { // (its ring is full -- a bucket that takes more than 64 of a tile's keys, tile after tile: one by one, from
+					// the end of the share backwards)
+					const unsigned long long g = atomicAdd(&tail[c], ~0ull) - 1ull;
 					out[g] = (uint16_t)k[u];
 				}
 			}
@@ -172,23 +189,27 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 			// (keys that found the ring full took numbers beyond it: given back)
 			const uint32_t cc = cnt[myc], first = cc >> 16, have = min(cc & 0xFFFFu, CAP), full = have >> 6; // whole half-rings: 0, 1 or 2
 			const unsigned long long g0 = dstp[myc];
+			const uint32_t sk0 = skip[myc];
 			unsigned long long jobs = __ballot(myhalf < full);
-			while (jobs) { // one half-ring = 64 values = 128 bytes per step, all lanes
+			while (jobs) { // one half-ring = 64 values = 128 bytes, aligned, per step
 				const int l = __builtin_ctzll(jobs);
 				jobs &= jobs - 1;
 				const uint32_t c = 32u * w + ((uint32_t)l & 31u), hf = (uint32_t)l >> 5;
 				const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)first, l);
-				const unsigned long long g = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)g0, l) |
-							      ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(g0 >> 32), l) << 32)) + 64u * hf;
+				const uint32_t sk = hf ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sk0, l);
+				const unsigned long long g = lane64(g0, l) + 64u * hf;
 				const uint16_t *src = buf + c * CAP + 64u * ((f0 + hf) & 1u);
-				if ((g & 1u) == 0) {
+				if (sk == 0) {
 					if (lane < 32) reinterpret_cast<uint32_t *>(out + g)[lane] = reinterpret_cast<const uint32_t *>(src)[lane];
-				} else
+				} else if (lane >= sk) // (the share's first block: its phantoms are not written)
 					out[g + lane] = src[lane];
 			}
 			if (myhalf == 0) {
 				cnt[myc] = (have - 64u * full) | (((first + full) & 1u) << 16);
-				if (full) dstp[myc] = g0 + 64u * full;
+				if (full) {
+					dstp[myc] = g0 + 64u * full;
+					skip[myc] = 0;
+				}
 			}
 		}
 		__syncthreads();
@@ -198,9 +219,9 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 	}
 	// ---- what is left: less than a half-ring per bucket
 	for (uint32_t c = 32u * w; c < 32u * w + 32u; ++c) {
-		const uint32_t cc = cnt[c], rem = cc & 0xFFFFu, first = cc >> 16; // (rem < 64)
+		const uint32_t cc = cnt[c], rem = cc & 0xFFFFu, first = cc >> 16, sk = skip[c]; // (rem < 64)
 		const unsigned long long g = dstp[c];
-		if (lane < rem) out[g + lane] = buf[c * CAP + 64u * first + lane];
+		if (lane >= sk && lane < rem) out[g + lane] = buf[c * CAP + 64u * first + lane];
 	}
 }
 
