@@ -32,7 +32,7 @@ constexpr uint32_t kS16Chunks = MSD_S16_CHUNKS; // workgroups per top-byte paren
 constexpr int kS16Vec = MSD_S16_VEC;            // 16-byte vectors per thread and tile
 constexpr int kS16Kpt = 4 * kS16Vec;            // keys per thread and tile
 constexpr uint32_t kS16Tile = kS16Th * kS16Kpt;
-constexpr size_t kS16Lds = (size_t)256 * kS16Cap * 2 + 256 * 8 + 256 * 8 + 256 * 4 + 256 * 4; // rings | places | ends | fill | skip
+constexpr size_t kS16Lds = (size_t)256 * kS16Cap * 2 + 256 * 8 + 256 * 8 + 256 * 4 + 256 * 4 + (kS16Th / 64) * 64; // rings | places | ends | fill | skip | a wave's job lanes
 static_assert(2 * kS16Lds <= 160 * 1024, "two workgroups per CU");
 
 // chunk j of parent p (the keys whose top byte is p lie in [pb[p], pb[p + 1])): whole 16-byte vectors of the parent's range
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 	unsigned long long *tail = dstp + 256;                                                     // the share's end: keys that find the ring full go there, backwards
 	uint32_t *cnt = reinterpret_cast<uint32_t *>(tail + 256);                                  // per bucket: values in the ring (phantoms included) | first half-ring << 16
 	uint32_t *skip = cnt + 256;                                                                // phantom values at the start of the ring's first half
+	uint8_t *joblane = reinterpret_cast<uint8_t *>(skip + 256) + 64 * (threadIdx.x >> 6);     // this wave's compacted job lanes
 	const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
 	const uint32_t p = blockIdx.x / kS16Chunks, j = blockIdx.x % kS16Chunks;
 	uint64_t a, b;
@@ -160,11 +161,21 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 	// a wave looks after buckets 32 w .. 32 w + 31: lane l after the first (l < 32) or second (l >= 32) unwritten half-ring
 	// of bucket 32 w + (l & 31)
 	const uint32_t myc = 32u * w + (lane & 31u), myhalf = lane >> 5;
+	MSD_STAMP_DECL(10);
+	MSD_STAMP_START();
 	auto lane64 = [&](unsigned long long x, int l) -> unsigned long long {
 		return (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l) |
 		       ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l) << 32);
 	};
 	for (uint64_t t0 = va; t0 < b; t0 += kS16Tile) {
+		MSD_STAMP(9);
+		MSD_STAMP_TICK(11);
+#ifdef MSD_STAMPS
+		if constexpr (kStampThis) { // (the wait for this tile's keys, apart from the work on them)
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			MSD_STAMP(0);
+		}
+#endif
 		uint32_t got[kS16Kpt];
 #pragma unroll
 		for (int u = 0; u < kS16Kpt; ++u) got[u] = atomicAdd(&cnt[(k[u] >> 16) & 255u], (okm >> u) & 1u); // (a key of another chunk adds nothing)
@@ -182,27 +193,48 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 			}
 		}
 		// the next tile's keys are on their way while this one's blocks are written
+		MSD_STAMP(1); // fetch-adds + ring stores
 		uint32_t kn[kS16Kpt], okn;
 		s16_load(keys, n, t0 + kS16Tile, a, b, tid, kn, okn);
+		MSD_STAMP(2); // next tile's loads issued
 		__syncthreads();
+		MSD_STAMP(3); // barrier
 		{
 			// (keys that found the ring full took numbers beyond it: given back)
 			const uint32_t cc = cnt[myc], first = cc >> 16, have = min(cc & 0xFFFFu, CAP), full = have >> 6; // whole half-rings: 0, 1 or 2
 			const unsigned long long g0 = dstp[myc];
 			const uint32_t sk0 = skip[myc];
-			unsigned long long jobs = __ballot(myhalf < full);
-			while (jobs) { // one half-ring = 64 values = 128 bytes, aligned, per step
-				const int l = __builtin_ctzll(jobs);
-				jobs &= jobs - 1;
-				const uint32_t c = 32u * w + ((uint32_t)l & 31u), hf = (uint32_t)l >> 5;
-				const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)first, l);
-				const uint32_t sk = hf ? 0u : (uint32_t)__builtin_amdgcn_readlane((int)sk0, l);
-				const unsigned long long g = lane64(g0, l) + 64u * hf;
-				const uint16_t *src = buf + c * CAP + 64u * ((f0 + hf) & 1u);
-				if (sk == 0) {
-					if (lane < 32) reinterpret_cast<uint32_t *>(out + g)[lane] = reinterpret_cast<const uint32_t *>(src)[lane];
-				} else if (lane >= sk) // (the share's first block: its phantoms are not written)
-					out[g + lane] = src[lane];
+			const bool job = myhalf < full;
+			// a share's first block has phantoms in front (once per share): one job per step, 2-byte stores
+			unsigned long long slow = __ballot(job && myhalf == 0 && sk0 != 0);
+			const unsigned long long fast = __ballot(job) & ~slow;
+			while (slow) {
+				const int l = __builtin_ctzll(slow);
+				slow &= slow - 1;
+				const uint32_t c = 32u * w + ((uint32_t)l & 31u);
+				const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)first, l), sk = (uint32_t)__builtin_amdgcn_readlane((int)sk0, l);
+				const unsigned long long g = lane64(g0, l);
+				const uint16_t *src = buf + c * CAP + 64u * (f0 & 1u);
+				if (lane >= sk) out[g + lane] = src[lane];
+			}
+			// every other half-ring = 64 values = 128 bytes to a 128-byte-aligned place: eight jobs per step, eight lanes of 16
+			// bytes per job (one job per step, a dependent LDS round trip each, took 3.6 of a tile's 9.4 thousand cycles)
+			const uint32_t nfast = (uint32_t)__builtin_popcountll(fast);
+			if (nfast) { // (uniform)
+				if ((fast >> lane) & 1ull) joblane[__builtin_popcountll(fast & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				for (uint32_t j0 = 0; j0 < nfast; j0 += 8) {
+					const uint32_t jq = j0 + (lane >> 3);
+					const uint32_t sl = joblane[min(jq, nfast - 1u)];
+					const uint32_t c = 32u * w + (sl & 31u), hf = sl >> 5;
+					const uint32_t f0 = (uint32_t)__shfl((int)first, (int)sl);
+					const unsigned long long g = ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)g0, (int)sl) |
+								      ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(g0 >> 32), (int)sl) << 32)) + 64u * hf;
+					if (jq < nfast) {
+						const u32x4 v = *reinterpret_cast<const u32x4 *>(buf + c * CAP + 64u * ((f0 + hf) & 1u) + 8u * (lane & 7u));
+						*reinterpret_cast<u32x4 *>(out + g + 8u * (lane & 7u)) = v;
+					}
+				}
 			}
 			if (myhalf == 0) {
 				cnt[myc] = (have - 64u * full) | (((first + full) & 1u) << 16);
@@ -212,11 +244,14 @@ __global__ __launch_bounds__(kS16Th, 2) void scatter_low16_kernel(const uint32_t
 				}
 			}
 		}
+		MSD_STAMP(4); // half-rings out
 		__syncthreads();
+		MSD_STAMP(5); // barrier
 #pragma unroll
 		for (int u = 0; u < kS16Kpt; ++u) k[u] = kn[u];
 		okm = okn;
 	}
+	MSD_STAMP_FLUSH(TH / 64);
 	// ---- what is left: less than a half-ring per bucket
 	for (uint32_t c = 32u * w; c < 32u * w + 32u; ++c) {
 		const uint32_t cc = cnt[c], rem = cc & 0xFFFFu, first = cc >> 16, sk = skip[c]; // (rem < 64)
