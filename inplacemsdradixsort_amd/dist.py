@@ -289,12 +289,12 @@ FINE_LOW16 = True
 FINE_HIST = True
 FINE_HIST_MIN_KEYS = 3 << 28     # 12288 keys per bucket: a record is then 0.7 of the bucket's low halves
 # ... and only up to this many ranks.  One GPU's measurements at 2^30 keys per rank (tools/multigpu_local_work.py,
-# profiles/r03_multigpu_local_work.jsonl): a rank's local work per step is 9.5 / 8.7 / 8.6 ms at 2 / 4 / 8 ranks with
-# records (order_low16 5.4 + pack 1.3 + leaf), 8.2 / 7.5 / 7.4 with low halves (order_low16 5.4 + leaf), while a pair of
+# profiles/r03_multigpu_local_work.jsonl): a rank's local work per step is 8.8 / 8.2 / 7.9 ms at 2 / 4 / 8 ranks with
+# records (order_low16 4.85 + pack 1.3 + leaf), 7.6 / 6.9 / 6.7 with low halves (order_low16 4.85 + leaf), while a pair of
 # GPUs -- ONE xGMI link, about 60 GB/s each way -- exchanges 4 n / G bytes as whole keys, half of that as low halves,
 # 1.06 n / G as records: at 2^30 keys 36 / 18 / 9.5 ms at 2 ranks, 18 / 9 / 4.8 at 4, 9 / 4.5 / 2.4 at 8.  Records where the
-# exchange would otherwise outlast the local work by far (2 ranks: 9.8 against 18 ms per step); low halves where it runs
-# level with it (4: about 9 ms either way) or hides behind it (8).
+# exchange would otherwise outlast the local work by far (2 ranks: 9.5 against 18 ms per step); low halves where it runs
+# level with it (4: 8.5-9 ms either way, depending on the links' real rate) or hides behind it (8).
 FINE_HIST_MAX_WORLD = 2
 HIST2_RECORD_BYTES = 17408
 
