@@ -52,8 +52,8 @@ int msd_shard_destroy(msd_shard *sh);
 /* "low16" (default 1): the fine scheme exchanges only the low halves of the keys -- the upper half of a key is its
  * bucket's number once the shard is ordered by it (msd_pack_low16_u32 / msd_merge_buckets_u32_low16): half the bytes over
  * xGMI for one more pass over the shard.  0 = whole keys travel.  All ranks must use the same value.
- * "hist" (default 1): at up to "hist_max_world" ranks (default 2: from 4 ranks on a pair's low halves take no longer over their
- * link than the local work they hide behind), when every rank holds at least "hist_min_keys" keys (default 3 * 2^28) and d_recv / d_work hold 2^16
+ * "hist" (default 1): at up to "hist_max_world" ranks (default 4: at 8 ranks a pair's low halves take less time over their link
+ * than the local work they hide behind), when every rank holds at least "hist_min_keys" keys (default 3 * 2^28) and d_recv / d_work hold 2^16
  * records, the buckets travel as HISTOGRAMS of their low halves (msd_hist2_pack_u32 / msd_merge_buckets_u32_hist2 of
  * msd_radix_hip.h: 17408 bytes per source and bucket, a quarter of the whole keys' bytes at 2^30 keys per rank); a rank
  * whose packing overflows (a bucket of more than 65535 keys, more than 255 values with three copies in one bucket) says

@@ -42,7 +42,7 @@ struct msd_shard {
 	bool low16 = true;           // fine scheme: only the low halves of the keys are exchanged ("low16" = 0: whole keys; all ranks alike)
 	bool hist = true;            // fine scheme: dense buckets are exchanged as histogram records ("hist" = 0: never; all ranks alike)
 	uint64_t hist_min = 3ull << 28; // ("hist_min_keys": tests)
-	int hist_max_world = 2;         // ("hist_max_world")
+	int hist_max_world = 4;         // ("hist_max_world")
 	uint32_t *d_flag = nullptr;
 	std::string err;
 };
@@ -327,8 +327,8 @@ int msd_sort_u32_sharded(msd_shard *sh, uint32_t *d_keys, uint64_t n, uint32_t *
 		// Dense buckets travel as HISTOGRAMS of their low halves (msd_hist2_pack_u32: one record of 17408 bytes per bucket,
 		// whatever it holds -- a quarter of the whole keys' bytes at 2^14 keys per bucket), packed into the work buffer; a rank
 		// whose packing did not overflow says so in its row, and the records travel only if every rank's did not.
-		// (at 2 ranks only: from 4 on a pair's low halves take about as long over their link as the local work they hide behind,
-		// and records cost 1.7 ms more to prepare -- the figures are in inplacemsdradixsort_amd/dist.py at FINE_HIST_MAX_WORLD)
+		// (up to 4 ranks: there a pair's low halves take longer over their link than the local work they hide behind; at 8 they
+		// do not, and records cost 1.3 ms more to prepare -- the figures are in inplacemsdradixsort_amd/dist.py at FINE_HIST_MAX_WORLD)
 		const bool want_hist = sh->hist && W <= sh->hist_max_world && n >= sh->hist_min && work_cap * 4 >= rec_total && recv_cap * 4 >= rec_total;
 		// Otherwise only the keys' LOW halves travel: once the shard is ordered by the upper halves, the upper half of a key is
 		// its bucket's number, which the receiver knows from the counts -- half the bytes over the links (one xGMI link per

@@ -291,11 +291,12 @@ FINE_HIST_MIN_KEYS = 3 << 28     # 12288 keys per bucket: a record is then 0.7 o
 # ... and only up to this many ranks.  One GPU's measurements at 2^30 keys per rank (tools/multigpu_local_work.py,
 # profiles/r03_multigpu_local_work.jsonl): a rank's local work per step is 8.8 / 8.2 / 7.9 ms at 2 / 4 / 8 ranks with
 # records (order_low16 4.85 + pack 1.3 + leaf), 7.6 / 6.9 / 6.7 with low halves (order_low16 4.85 + leaf), while a pair of
-# GPUs -- ONE xGMI link, about 60 GB/s each way -- exchanges 4 n / G bytes as whole keys, half of that as low halves,
-# 1.06 n / G as records: at 2^30 keys 36 / 18 / 9.5 ms at 2 ranks, 18 / 9 / 4.8 at 4, 9 / 4.5 / 2.4 at 8.  Records where the
-# exchange would otherwise outlast the local work by far (2 ranks: 9.5 against 18 ms per step); low halves where it runs
-# level with it (4: 8.5-9 ms either way, depending on the links' real rate) or hides behind it (8).
-FINE_HIST_MAX_WORLD = 2
+# GPUs -- ONE xGMI link, 76.8 GB/s each way at best, 55-60 expected of an all-to-all -- exchanges 4 n / G bytes as whole
+# keys, half of that as low halves, 1.06 n / G as records: at 2^30 keys and 58 GB/s 37 / 18.5 / 9.8 ms at 2 ranks, 18.5 / 9.3
+# / 4.9 at 4, 9.3 / 4.6 / 2.5 at 8.  Records where the low halves would take longer over the link than the local work they
+# hide behind (2 ranks: 9.8 against 18.5 ms per step; 4 ranks: 8.5 against 9.3 -- a tie if the links reach 66 GB/s);
+# low halves where the exchange hides either way (8 ranks).
+FINE_HIST_MAX_WORLD = 4
 HIST2_RECORD_BYTES = 17408
 
 
