@@ -889,7 +889,11 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 	};
 	u32x4 q[U]; // the first batch of the bucket at hand: requested while the bucket before it is packed
 	if (blockIdx.x < nb) load_batch(where(blockIdx.x), where(blockIdx.x).vfirst, tid0, q);
+	MSD_STAMP_DECL(11);
+	MSD_STAMP_START();
 	for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+		MSD_STAMP(9);
+		MSD_STAMP_TICK(11);
 		uint32_t tid = tid0;
 		asm volatile("" : "+v"(tid));
 		const Where wb = where(b);
@@ -901,7 +905,15 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 			bad[0] = fits ? 0u : 1u;
 			bad[1] = 0;
 		}
+		MSD_STAMP(0); // clear
 		__syncthreads();
+		MSD_STAMP(1); // barrier
+#ifdef MSD_STAMPS
+		if constexpr (kStampThis) {
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			MSD_STAMP(2); // wait for the bucket's keys
+		}
+#endif
 		// (fetch-adds without return value; a counter that has spilled into its neighbour shows in the sum of all bytes below)
 		auto count = [&](uint32_t key) {
 			const uint32_t v = key & 0xFFFFu;
@@ -935,11 +947,14 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 			load_batch(wb, v0, tid, q2);
 			eat(q2, v0);
 		}
+		MSD_STAMP(3); // fetch-adds
 		{ // the next bucket's first batch is on its way while this one is packed (past the last bucket: the last one again, unused)
 			const Where wn = where(min(b + gridDim.x, nb - 1u));
 			load_batch(wn, wn.vfirst, tid, q);
 		}
+		MSD_STAMP(4); // next loads issued
 		__syncthreads();
+		MSD_STAMP(5); // barrier
 		// ---- thread t packs values [128 t, 128 t + 128) = 32 counter words into 32 bytes of fields
 		const u32x4 *cq = reinterpret_cast<const u32x4 *>(cw + h2_at(tid * 32u));
 		uint32_t out[8], bsum = 0, many = 0; // many: bit = a word of mine that holds a value with three or more copies
@@ -950,13 +965,18 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 			uint32_t o4 = 0;
 #pragma unroll
 			for (int i = 0; i < 4; ++i) {
-				// per byte: min(count, 3) -- 3 where any of the bits 2..7 is set, the low two bits otherwise
-				const uint32_t w = wq[i], hi = w & 0xFCFCFCFCu;
-				bsum += (w & 0x00FF00FFu) + ((w >> 8) & 0x00FF00FFu); // (two 16-bit lanes: 128 bytes of at most 255 fit)
-				const uint32_t nz = ((((hi & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | hi) & 0x80808080u) >> 7;
-				const uint32_t f = (w & 0x03030303u) | (nz * 3u);
-				o4 |= ((f | (f >> 6) | (f >> 12) | (f >> 18)) & 0xFFu) << (8 * i);
-				many |= (f & (f >> 1) & 0x01010101u) != 0u ? 1u << (4 * j + i) : 0u;
+				// per byte min(count, 3): the four bytes as two pairs of 16-bit lanes, one packed minimum each (the first
+				// version clamped bytes with seven SWAR operations: the packing loop was VALU-bound, 7-11 of a bucket's 20
+				// thousand cycles)
+				typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+				const uint32_t w = wq[i];
+				bsum = __builtin_amdgcn_sad_u8(w, 0u, bsum); // + the four bytes
+				const uint32_t e02 = w & 0x00FF00FFu, e13 = (w >> 8) & 0x00FF00FFu; // counts of values 0, 2 | 1, 3 of the word
+				const us2 three = { 3, 3 };
+				const us2 m02 = __builtin_elementwise_min(__builtin_bit_cast(us2, e02), three), m13 = __builtin_elementwise_min(__builtin_bit_cast(us2, e13), three);
+				const uint32_t t = __builtin_bit_cast(uint32_t, m02) | (__builtin_bit_cast(uint32_t, m13) << 2); // bits 0..3: values 0, 1; bits 16..19: values 2, 3
+				o4 |= ((t & 0xFu) | ((t >> 12) & 0xF0u)) << (8 * i);
+				many |= (t & (t >> 1) & 0x00050005u) != 0u ? 1u << (4 * j + i) : 0u;
 			}
 			out[j] = o4;
 		}
@@ -975,7 +995,7 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 			}
 		}
 		{ // the bytes must add up to the bucket's keys: a counter that passed 255 has carried into its neighbour (or out of its word)
-			uint32_t t = (bsum & 0xFFFFu) + (bsum >> 16);
+			uint32_t t = bsum;
 #pragma unroll
 			for (int o2 = 32; o2 > 0; o2 >>= 1) t += (uint32_t)__shfl_xor((int)t, o2);
 			if ((tid & 63u) == 0) atomicAdd(&bad[1], t);
@@ -983,14 +1003,18 @@ __global__ __launch_bounds__(kH2Th, 2) void hist2_pack_kernel(const IN *__restri
 		unsigned char *r = rec + (size_t)b * kH2Rec;
 		__builtin_nontemporal_store(u32x4{ out[0], out[1], out[2], out[3] }, reinterpret_cast<u32x4 *>(r) + 2 * tid);
 		__builtin_nontemporal_store(u32x4{ out[4], out[5], out[6], out[7] }, reinterpret_cast<u32x4 *>(r) + 2 * tid + 1);
+		MSD_STAMP(6); // pack + entries + fields out
 		__syncthreads();
+		MSD_STAMP(7); // barrier
 		if (tid < (kH2MaxExc + 1) / 4) {
 			const u32x4 q = reinterpret_cast<const u32x4 *>(exc)[tid];
 			if (tid == 0 && (q.x > kH2MaxExc || bad[0] != 0 || bad[1] != n)) atomicOr(overflow, 1u);
 			reinterpret_cast<u32x4 *>(r + kH2Fields)[tid] = q;
 		}
 		__syncthreads();
+		MSD_STAMP(8); // entries out + barrier
 	}
+	MSD_STAMP_FLUSH(TH / 64);
 }
 
 // first index i with (keys[i] >> shift) >= first + b, b = 0 .. nbuckets: the boundaries of the buckets of an array that
